@@ -1,0 +1,180 @@
+/*
+ * hx.h -- C ABI of the MI355X-native hybrid retrieval engine (libhx.so).
+ *
+ * This is the drop-in boundary for the Qdrant-backed search path of
+ * VivekMalipatel/RAG_Application.  The reference has no FFI of its own: its
+ * seam is the Python class QdrantHandler, which forwards every operation to a
+ * Qdrant server over HTTP.  Each entry point below cites the reference call it
+ * replaces (paths relative to the reference root).  INTEGRATION.md shows the
+ * ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from hx_last_error() (thread-local).
+ *   - "host" pointers are ordinary process memory; "dev" pointers are HIP device
+ *     memory on the index's device.  `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  Device entry points enqueue work on
+ *     `stream`; they synchronise it only where stated.
+ *   - a ranked list is exchanged between stages as an array of 64-bit KEYS,
+ *     `keys[b*stride + r]`, r = rank, sorted best-first, with `counts[b]` valid
+ *     entries; key = (orderable(score) << 32) | (0xFFFFFFFF - id), so that the
+ *     descending integer order IS the engine's total order (score descending,
+ *     id ascending).  0 marks an empty slot.  ids are global row ids
+ *     (id_base + local row), < 2^32 - 1.
+ *   - no torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef HX_H
+#define HX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HX_ABI_VERSION 1
+
+typedef struct hx_index hx_index;
+
+/* The 8-key search_params contract
+ * (app/services/agents/hybrid_search_workflow.py:8-19,
+ *  app/api/v1/endpoints/mcp/qdrant_search_mcp_endpoint.py:19-28) plus the
+ * switches for semantics inherited from Qdrant (oracle/oracle.py names them). */
+typedef struct hx_params {
+  int32_t matryoshka_64_limit;   /* limit of the innermost prefix stage (first matryoshka size)   */
+  int32_t matryoshka_128_limit;  /* second prefix stage                                           */
+  int32_t matryoshka_256_limit;  /* third prefix stage                                            */
+  int32_t dense_limit;
+  int32_t quantized_limit;
+  int32_t sparse_limit;
+  int32_t final_limit;
+  int32_t hnsw_ef;               /* accepted, unused: every stage is exact (qdrant_handler.py:369) */
+  float   rrf_k;                 /* 2.0  : Qdrant RRF constant                                      */
+  int32_t rrf_rank_base;         /* 0    : 0-based ranks                                            */
+  int32_t rrf_limit;             /* 10   : default limit of a Prefetch without `limit`              */
+  int32_t mode;                  /* HX_MODE_TREE or HX_MODE_H1                                      */
+} hx_params;
+
+#define HX_MODE_TREE 0  /* the reference query tree, qdrant_handler.py:305-372                  */
+#define HX_MODE_H1   1  /* dense top-dense_limit (+) sparse top-sparse_limit -> RRF -> final_limit */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* create_collection (qdrant_handler.py:24-117): one index = one user collection
+ * holding the named vectors dense / quantized / matryoshka_* and the sparse
+ * vector.  `msizes` = matryoshka prefix sizes (ascending, <= 3 of them, each a
+ * multiple of 64 and <= dim); n_msizes may be 0.  `id_base` = global id of local
+ * row 0 (row sharding).  `device` = HIP device ordinal. */
+int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t device,
+              int64_t id_base, hx_index** out);
+/* delete_collection (qdrant_handler.py:430-439) */
+int hx_destroy(hx_index* h);
+const char* hx_last_error(void);
+int hx_abi_version(void);
+
+/* ---- ingest: store_document_vectors / store_chat_vectors ------------------
+ * (qdrant_handler.py:120-198, 200-267 -> AsyncQdrantClient.upsert :190-193) */
+
+/* optional: pre-size device storage for `n_rows` rows and `nnz` sparse entries */
+int hx_reserve(hx_index* h, int64_t n_rows, int64_t nnz);
+/* append n raw dense rows [n x dim] (host fp32).  Derives on device, per row:
+ * the L2-normalised "dense" vector, the normalised prefixes, the int8
+ * "quantized" copy trunc(127*x) (qdrant_handler.py:144-150) and its norm. */
+int hx_add_dense(hx_index* h, const float* rows_host, int64_t n);
+/* append the sparse vectors of the same n rows as doc-major CSR (host):
+ * indptr[n+1], idx[nnz] (term ids in [0, 2^31)), val[nnz].  Indices must be
+ * unique within a row (Qdrant rejects duplicates).  Rows must be added in the
+ * same order as hx_add_dense; a row may be empty. */
+int hx_add_sparse(hx_index* h, const int64_t* indptr_host, const int32_t* idx_host,
+                  const float* val_host, int64_t n);
+/* build the on-device inverted index over everything added so far; searches
+ * call it implicitly when the index is stale. */
+int hx_finalize(hx_index* h);
+/* get_collection_chunk_count (qdrant_handler.py:441-481) */
+int hx_count(hx_index* h, int64_t* n_rows);
+int hx_nnz(hx_index* h, int64_t* nnz);
+
+/* fill rows [row0, row0+n) with the synthetic corpus of SURVEY.md 8(d),
+ * generated on the device (oracle/oracle.py synth_dense / synth_sparse_docs give
+ * the same values).  Global row r = id_base + local row.  cdf_u32[V] and
+ * len_u16[256] are the shared lookup tables (host).  with_sparse=0 skips the
+ * sparse side. */
+int hx_synth_fill(hx_index* h, int64_t n, uint32_t seed_dense, uint32_t seed_sparse,
+                  const uint32_t* cdf_u32_host, int32_t V, const uint16_t* len_u16_host,
+                  int32_t with_sparse);
+/* synthetic query batch on the device: q_dev [B x dim] fp32 rows q0..q0+B-1 */
+int hx_synth_queries_dense(int32_t dim, int64_t q0, int32_t B, uint32_t seed,
+                           float* q_dev, void* stream);
+
+/* ---- whole-collection stages (device in, device out) ---------------------- */
+
+/* Prefetch(query=dense_vector[:prefix], using="matryoshka_<prefix>"|"dense", limit)
+ * (qdrant_handler.py:311-315, 327-329, 366-368).  q_dev: B raw (un-normalised)
+ * query rows [B x dim] fp32.  prefix = 0 searches the full vector.  Output: keys
+ * [B x limit] + counts[B].  Synchronises `stream` (exactness certificate). */
+int hx_search_dense(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, int32_t limit,
+                    uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+/* Prefetch(query=quantized_query, using="quantized", limit) (qdrant_handler.py:299-302,335-339) */
+int hx_search_i8(hx_index* h, const float* q_dev, int32_t B, int32_t limit,
+                 uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+/* Prefetch(query=SparseVector, using="sparse", limit) (qdrant_handler.py:347-354).
+ * Query batch as CSR on the device: indptr[B+1] (int64), idx (int32, ascending and
+ * unique within a query), val (fp32). */
+int hx_search_sparse(hx_index* h, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
+                     const float* q_val_dev, int32_t B, int32_t max_terms, int32_t limit,
+                     uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+
+/* ---- candidate stages ------------------------------------------------------ */
+
+/* outer level of a nested Prefetch / the root query (qdrant_handler.py:307-330,
+ * 333-344, 363-372): re-score the candidate ids in cand_keys (scores ignored, ids
+ * outside this shard skipped, duplicates merged) with one named vector and keep
+ * `limit`. */
+int hx_rescore(hx_index* h, const float* q_dev, int32_t B, int32_t prefix,
+               const uint64_t* cand_keys_dev, int32_t cand_stride, const int32_t* cand_counts_dev,
+               int32_t limit, uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+/* FusionQuery(Fusion.RRF) over two ranked lists (qdrant_handler.py:357-360) */
+int hx_rrf(int32_t device, const uint64_t* a_keys_dev, int32_t a_stride, const int32_t* a_counts_dev,
+           const uint64_t* b_keys_dev, int32_t b_stride, const int32_t* b_counts_dev,
+           int32_t B, float rrf_k, int32_t rank_base, int32_t limit,
+           uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+/* union / cross-shard merge: per query, top `limit` of the `stride` slots of
+ * in_keys (0 = empty), duplicates optionally dropped.  in_counts may be NULL
+ * (then every slot is examined). */
+int hx_merge(int32_t device, const uint64_t* in_keys_dev, int32_t stride, const int32_t* in_counts_dev,
+             int32_t B, int32_t limit, int32_t dedupe,
+             uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+/* keys -> (fp32 score, int64 id); empty slots give (-inf, -1) */
+int hx_unpack(int32_t device, const uint64_t* keys_dev, int64_t n, float* scores_dev,
+              int64_t* ids_dev, void* stream);
+
+/* ---- whole query, one shard (host in, host out) ----------------------------
+ * QdrantHandler.hybrid_search -> query_points (qdrant_handler.py:296-372).
+ * q_dense_host [B x dim] raw queries; sparse queries as CSR (indices need not be
+ * sorted).  Outputs: scores/ids [B x final_limit], counts[B]. */
+int hx_hybrid_query_host(hx_index* h, const float* q_dense_host,
+                         const int64_t* q_indptr_host, const int32_t* q_idx_host,
+                         const float* q_val_host, int32_t B, const hx_params* p,
+                         float* scores_host, int64_t* ids_host, int32_t* counts_host);
+/* same, device-resident inputs and outputs (bench path; sparse idx sorted) */
+int hx_hybrid_query_dev(hx_index* h, const float* q_dense_dev,
+                        const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
+                        const float* q_val_dev, int32_t B, int32_t max_terms, const hx_params* p,
+                        uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+
+/* ---- introspection (tests, bench) ------------------------------------------ */
+typedef struct hx_stats {
+  int64_t n_rows, nnz, n_segments, n_groups, hash_capacity;
+  int64_t bytes_dense_f32, bytes_dense_f16, bytes_i8, bytes_prefix, bytes_sparse;
+  int64_t dense_fallback_queries;   /* queries whose certificate failed so far */
+  int64_t i8_fallback_queries;
+} hx_stats;
+int hx_get_stats(hx_index* h, hx_stats* out);
+/* copy the derived row `row` (local) of one named vector to the host:
+ * which = 0 dense f32 [dim], 1..3 prefix f32 [msizes[which-1]], 4 int8 [dim] */
+int hx_debug_row(hx_index* h, int32_t which, int64_t row, void* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HX_H */

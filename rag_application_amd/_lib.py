@@ -1,0 +1,95 @@
+"""ctypes binding of include/hx.h.  The product has NO CPU path: a missing or
+unloadable libhx.so raises, and every entry point needs a HIP device."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhx.so")
+
+HX_MODE_TREE = 0
+HX_MODE_H1 = 1
+
+
+class HxError(RuntimeError):
+    pass
+
+
+class HxParams(C.Structure):
+    _fields_ = [
+        ("matryoshka_64_limit", C.c_int32),
+        ("matryoshka_128_limit", C.c_int32),
+        ("matryoshka_256_limit", C.c_int32),
+        ("dense_limit", C.c_int32),
+        ("quantized_limit", C.c_int32),
+        ("sparse_limit", C.c_int32),
+        ("final_limit", C.c_int32),
+        ("hnsw_ef", C.c_int32),
+        ("rrf_k", C.c_float),
+        ("rrf_rank_base", C.c_int32),
+        ("rrf_limit", C.c_int32),
+        ("mode", C.c_int32),
+    ]
+
+
+class HxStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "n_rows", "nnz", "n_segments", "n_groups", "hash_capacity", "bytes_dense_f32",
+        "bytes_dense_f16", "bytes_i8", "bytes_prefix", "bytes_sparse",
+        "dense_fallback_queries", "i8_fallback_queries")]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "hx_create": [C.c_int32, _P, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_P)],
+    "hx_destroy": [_P],
+    "hx_abi_version": [],
+    "hx_reserve": [_P, C.c_int64, C.c_int64],
+    "hx_add_dense": [_P, _P, C.c_int64],
+    "hx_add_sparse": [_P, _P, _P, _P, C.c_int64],
+    "hx_finalize": [_P],
+    "hx_count": [_P, C.POINTER(C.c_int64)],
+    "hx_nnz": [_P, C.POINTER(C.c_int64)],
+    "hx_synth_fill": [_P, C.c_int64, C.c_uint32, C.c_uint32, _P, C.c_int32, _P, C.c_int32],
+    "hx_synth_queries_dense": [C.c_int32, C.c_int64, C.c_int32, C.c_uint32, _P, _P],
+    "hx_search_dense": [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P],
+    "hx_search_i8": [_P, _P, C.c_int32, C.c_int32, _P, _P, _P],
+    "hx_search_sparse": [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P],
+    "hx_rescore": [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, _P],
+    "hx_rrf": [C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_float, C.c_int32,
+               C.c_int32, _P, _P, _P],
+    "hx_merge": [C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P],
+    "hx_unpack": [C.c_int32, _P, C.c_int64, _P, _P, _P],
+    "hx_hybrid_query_host": [_P, _P, _P, _P, _P, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
+    "hx_hybrid_query_dev": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
+    "hx_get_stats": [_P, C.POINTER(HxStats)],
+    "hx_debug_row": [_P, C.c_int32, C.c_int64, _P],
+}
+EXPORTS = tuple(_SIGS) + ("hx_last_error",)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HxError(f"{LIB_PATH} is missing: run `python -m rag_application_amd.build` "
+                          "(the engine has no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            f = getattr(l, name)
+            f.argtypes = args
+            f.restype = C.c_int
+        l.hx_last_error.argtypes = []
+        l.hx_last_error.restype = C.c_char_p
+        if l.hx_abi_version() != 1:
+            raise HxError("libhx ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise HxError(lib().hx_last_error().decode("utf-8", "replace"))

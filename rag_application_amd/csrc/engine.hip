@@ -1,0 +1,946 @@
+// Host-side engine: device storage for one collection, stage orchestration, C ABI.
+//
+// The stage functions restate the nested-Prefetch query of the reference
+// (app/core/vector_store/qdrant/qdrant_handler.py:296-372) as launches on one HIP
+// stream.  See include/hx.h for the boundary and DESIGN.md for the algorithms.
+#include "../../include/hx.h"
+#include "hx_common.hpp"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <numeric>
+#include <vector>
+
+namespace hx {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+struct Workspace {
+  std::map<int, std::pair<void*, size_t>> slots;
+  void* get(int id, size_t bytes) {
+    auto& s = slots[id];
+    if (s.second < bytes) {
+      if (s.first) HX_HIP(hipFree(s.first));
+      s.first = nullptr;
+      s.second = 0;
+      const size_t want = (bytes + 255) / 256 * 256;
+      HX_HIP(hipMalloc(&s.first, want));
+      s.second = want;
+    }
+    return s.first;
+  }
+  void release() {
+    for (auto& kv : slots)
+      if (kv.second.first) (void)hipFree(kv.second.first);
+    slots.clear();
+  }
+};
+
+enum WsSlot {
+  WS_QN = 1, WS_QH, WS_Q8, WS_RINVQ, WS_CAND, WS_CAND2, WS_CNT, WS_CNT2, WS_OVF, WS_TAU, WS_FAIL,
+  WS_NFAIL, WS_QSEL, WS_FB_KEYS, WS_FB_CNT, WS_FB_INCNT, WS_SP_PARTS, WS_SP_PCNT, WS_RAW, WS_RS_TMP,
+  WS_T_A, WS_T_ACNT, WS_T_B, WS_T_BCNT, WS_T_C, WS_T_CCNT, WS_T_D, WS_T_DCNT, WS_T_E, WS_T_ECNT,
+  WS_T_F, WS_T_FCNT, WS_T_G, WS_T_GCNT, WS_H_QD, WS_H_QIP, WS_H_QIX, WS_H_QV, WS_H_OUT, WS_H_OCNT,
+  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC
+};
+
+template <typename T>
+static void grow_copy(T*& p, int64_t old_elems, int64_t new_elems, bool zero_tail) {
+  T* np_ = nullptr;
+  HX_HIP(hipMalloc((void**)&np_, (size_t)std::max<int64_t>(new_elems, 1) * sizeof(T)));
+  if (zero_tail) HX_HIP(hipMemset(np_, 0, (size_t)std::max<int64_t>(new_elems, 1) * sizeof(T)));
+  if (p && old_elems > 0) HX_HIP(hipMemcpy(np_, p, (size_t)old_elems * sizeof(T), hipMemcpyDeviceToDevice));
+  if (p) HX_HIP(hipFree(p));
+  p = np_;
+}
+
+}  // namespace hx
+
+using namespace hx;
+
+struct hx_index {
+  int dim = 0, dim_pad = 0, dim_pad8 = 0, device = 0;
+  int n_pre = 0;
+  int psize[3] = {0, 0, 0};
+  int64_t id_base = 0;
+  int64_t n = 0, cap = 0;
+  float* dense = nullptr;
+  _Float16* dense_h = nullptr;
+  int8_t* q8 = nullptr;
+  float* q8_rinv = nullptr;
+  float* pre[3] = {nullptr, nullptr, nullptr};
+  _Float16* pre_h0 = nullptr;
+  // doc-major sparse staging (device)
+  int64_t* sp_indptr = nullptr;  // [sp_rows_cap + 1]
+  int32_t* sp_idx = nullptr;
+  float* sp_val = nullptr;
+  int64_t sp_rows = 0, sp_rows_cap = 0, nnz = 0, nnz_cap = 0;
+  bool sparse_stale = false;
+  SparseBuildOut sp{};
+  int n_segments = 0;
+  int64_t sp_docs_built = 0;
+  Workspace ws;
+  int64_t dense_fallbacks = 0, i8_fallbacks = 0;
+
+  void set_device() const { HX_HIP(hipSetDevice(device)); }
+};
+
+namespace hx {
+
+// ---------------------------------------------------------------------------------
+// storage
+// ---------------------------------------------------------------------------------
+static void reserve_rows(hx_index* h, int64_t want) {
+  if (want <= h->cap) return;
+  int64_t nc = std::max<int64_t>(want, h->cap * 2);
+  nc = round_up(nc, 256);
+  const int64_t n = h->n;
+  grow_copy(h->dense, n * h->dim_pad, nc * h->dim_pad, false);
+  grow_copy(h->dense_h, n * h->dim_pad, nc * h->dim_pad, false);
+  grow_copy(h->q8, n * h->dim_pad8, nc * h->dim_pad8, false);
+  grow_copy(h->q8_rinv, n, nc + 256, true);
+  for (int p = 0; p < h->n_pre; ++p) grow_copy(h->pre[p], n * h->psize[p], nc * h->psize[p], false);
+  if (h->n_pre > 0) grow_copy(h->pre_h0, n * h->psize[0], nc * h->psize[0], false);
+  h->cap = nc;
+}
+
+static void reserve_sparse(hx_index* h, int64_t rows, int64_t nnz) {
+  if (rows > h->sp_rows_cap) {
+    int64_t nc = std::max<int64_t>(rows, h->sp_rows_cap * 2);
+    nc = round_up(nc, 256);
+    grow_copy(h->sp_indptr, h->sp_rows + 1, nc + 2, true);
+    h->sp_rows_cap = nc;
+  }
+  if (nnz > h->nnz_cap) {
+    int64_t nc = std::max<int64_t>(nnz, h->nnz_cap * 2);
+    nc = round_up(nc, 1024);
+    grow_copy(h->sp_idx, h->nnz, nc, false);
+    grow_copy(h->sp_val, h->nnz, nc, false);
+    h->nnz_cap = nc;
+  }
+}
+
+static void prep_rows_device(hx_index* h, const float* raw_dev, int64_t n, hipStream_t st) {
+  PrepRowsArgs a{};
+  a.raw = raw_dev;
+  a.dim = h->dim;
+  a.dim_pad = h->dim_pad;
+  a.n = n;
+  a.dense = h->dense + h->n * h->dim_pad;
+  a.dense_h = h->dense_h + h->n * h->dim_pad;
+  a.q8 = h->q8 + h->n * h->dim_pad8;
+  a.dim_pad8 = h->dim_pad8;
+  a.q8_rinv = h->q8_rinv + h->n;
+  a.n_prefix = h->n_pre;
+  for (int p = 0; p < h->n_pre; ++p) {
+    a.psize[p] = h->psize[p];
+    a.pre[p] = h->pre[p] + h->n * h->psize[p];
+  }
+  a.pre_h0 = h->n_pre > 0 ? h->pre_h0 + h->n * h->psize[0] : nullptr;
+  launch_prep_rows(a, st);
+}
+
+static void free_sparse_index(hx_index* h) {
+  if (h->sp.doc_local) (void)hipFree(h->sp.doc_local);
+  if (h->sp.w) (void)hipFree(h->sp.w);
+  if (h->sp.table) (void)hipFree(h->sp.table);
+  h->sp = SparseBuildOut{};
+  h->n_segments = 0;
+  h->sp_docs_built = 0;
+}
+
+static void finalize(hx_index* h, hipStream_t st) {
+  if (!h->sparse_stale) return;
+  free_sparse_index(h);
+  if (h->nnz > 0) {
+    // rows added without a sparse vector are empty documents
+    const int64_t rows = std::max(h->sp_rows, h->n);
+    if (rows > h->sp_rows) {
+      reserve_sparse(h, rows, h->nnz);
+      std::vector<int64_t> tail((size_t)(rows - h->sp_rows), h->nnz);
+      HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows + 1, tail.data(), tail.size() * 8, hipMemcpyHostToDevice));
+      h->sp_rows = rows;
+    }
+    build_sparse_index(h->sp_indptr, h->sp_idx, h->sp_val, h->sp_rows, h->nnz, &h->sp, st);
+    h->n_segments = (int)((h->sp_rows + SEG_DOCS - 1) / SEG_DOCS);
+    h->sp_docs_built = h->sp_rows;
+  }
+  h->sparse_stale = false;
+}
+
+// ---------------------------------------------------------------------------------
+// per-search candidate geometry
+// ---------------------------------------------------------------------------------
+struct Geometry {
+  int Lp;     // candidates kept by the approximate pass
+  int C;      // per-query buffer capacity (power of two <= CAND_CAP)
+  int grow;   // chunk growth factor
+};
+static Geometry geometry(int L, bool approx) {
+  Geometry g;
+  g.Lp = approx ? L + std::max(32, L / 2) : L;
+  int c = next_pow2(std::max(8 * g.Lp, 1024));
+  g.C = std::min(c, CAND_CAP);
+  HX_CHECK(g.Lp * 2 <= g.C, "limit too large");
+  g.grow = 1 + (int)(0.7 * (g.C - g.Lp) / g.Lp);
+  if (g.grow < 2) g.grow = 2;
+  return g;
+}
+
+struct MatrixRef {
+  const float* m32;
+  const _Float16* m16;
+  int d, dpad;
+};
+static MatrixRef pick_matrix(hx_index* h, int prefix) {
+  if (prefix == 0)
+    return MatrixRef{h->dense, h->dense_h, h->dim, h->dim_pad};
+  for (int p = 0; p < h->n_pre; ++p)
+    if (h->psize[p] == prefix) return MatrixRef{h->pre[p], p == 0 ? h->pre_h0 : nullptr, prefix, prefix};
+  throw Error("unknown prefix size " + std::to_string(prefix));
+}
+
+static void zero_outputs(uint64_t* keys, int* cnt, int B, int L, hipStream_t st) {
+  HX_HIP(hipMemsetAsync(keys, 0, (size_t)B * L * 8, st));
+  HX_HIP(hipMemsetAsync(cnt, 0, (size_t)B * 4, st));
+}
+
+// scan all rows with geometric chunks; leaves the best `keep` keys (sorted) in cand
+static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t* Q, int64_t row_bytes, int B,
+                         int bn, const Geometry& g, uint64_t* cand, int* cnt, int* ovf, float* tau,
+                         const float* rinv_q, hipStream_t st) {
+  launch_fill_f32(tau, B, -std::numeric_limits<float>::infinity(), st);
+  HX_HIP(hipMemsetAsync(cnt, 0, (size_t)B * 4, st));
+  HX_HIP(hipMemsetAsync(ovf, 0, (size_t)B * 4, st));
+  ScanArgs a{};
+  a.A = A;
+  a.Q = Q;
+  a.row_bytes = row_bytes;
+  a.B = B;
+  a.nq_tiles = (int)(round_up(B, bn) / bn);
+  a.tau = tau;
+  a.cand = cand;
+  a.cnt = cnt;
+  a.overflow = ovf;
+  a.cap = g.C;
+  a.id_base = h->id_base;
+  a.rinv_x = h->q8_rinv;
+  a.rinv_q = rinv_q;
+  int64_t r0 = 0, r1 = std::min<int64_t>(h->n, g.C);
+  while (r0 < h->n) {
+    a.row_begin = r0;
+    a.row_end = r1;
+    launch_scan(a, kind, bn, st);
+    launch_compact(cand, g.C, cnt, B, g.Lp, 0, cand, g.C, cnt, tau, g.C, st);
+    r0 = r1;
+    // rows per launch bounded so the kernel's 32-bit tile counters cannot wrap
+    const int64_t next = std::min<int64_t>(r1 * g.grow, r1 + (1ll << 27));
+    r1 = std::min<int64_t>(h->n, next);
+  }
+}
+
+// exact fallback for selected queries: stream all rows through the spec arithmetic
+static void exact_range_fallback(hx_index* h, int kind, const void* M, int64_t row_stride, int dim_pad,
+                                 const void* Qp, int64_t q_stride, const float* rinv_q,
+                                 const std::vector<int>& sel, int L, uint64_t* out_keys, int* out_cnt,
+                                 hipStream_t st) {
+  const int nsel = (int)sel.size();
+  if (!nsel) return;
+  int* qsel = (int*)h->ws.get(WS_QSEL, (size_t)nsel * 4);
+  HX_HIP(hipMemcpyAsync(qsel, sel.data(), (size_t)nsel * 4, hipMemcpyHostToDevice, st));
+  const int C = CAND_CAP;
+  uint64_t* buf = (uint64_t*)h->ws.get(WS_FB_KEYS, (size_t)nsel * C * 8);
+  int* cnt = (int*)h->ws.get(WS_FB_CNT, (size_t)nsel * 4);
+  int* incnt = (int*)h->ws.get(WS_FB_INCNT, (size_t)nsel * 4);
+  HX_HIP(hipMemsetAsync(buf, 0, (size_t)nsel * C * 8, st));
+  RangeArgs ra{};
+  ra.r.kind = kind;
+  ra.r.M = M;
+  ra.r.row_stride = row_stride;
+  ra.r.dim_pad = dim_pad;
+  ra.r.Q = Qp;
+  ra.r.q_stride = q_stride;
+  ra.r.rinv_x = h->q8_rinv;
+  ra.r.rinv_q = rinv_q;
+  ra.r.n_rows = h->n;
+  ra.r.id_base = h->id_base;
+  ra.r.out = buf;
+  ra.r.stride = C;
+  ra.qsel = qsel;
+  ra.nsel = nsel;
+  ra.slot0 = L;
+  const int64_t CH = C - L;
+  for (int64_t r0 = 0; r0 < h->n; r0 += CH) {
+    const int64_t r1 = std::min<int64_t>(h->n, r0 + CH);
+    ra.row_begin = r0;
+    ra.row_end = r1;
+    launch_rescore_range(ra, st);
+    launch_fill_i32(incnt, nsel, (int)(L + (r1 - r0)), st);
+    launch_compact(buf, C, incnt, nsel, L, 0, buf, C, cnt, nullptr, C, st);
+  }
+  // scatter rows back: out_keys[sel[f]] = buf[f][0..L)
+  for (int f = 0; f < nsel; ++f) {
+    HX_HIP(hipMemcpyAsync(out_keys + (int64_t)sel[f] * L, buf + (int64_t)f * C, (size_t)L * 8,
+                          hipMemcpyDeviceToDevice, st));
+    HX_HIP(hipMemcpyAsync(out_cnt + sel[f], cnt + f, 4, hipMemcpyDeviceToDevice, st));
+  }
+}
+
+static std::vector<int> read_failures(hx_index* h, int* fail, int* nfail, int B, hipStream_t st) {
+  int nf = 0;
+  HX_HIP(hipMemcpyAsync(&nf, nfail, 4, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  std::vector<int> sel;
+  if (nf > 0) {
+    std::vector<int> f((size_t)B);
+    HX_HIP(hipMemcpy(f.data(), fail, (size_t)B * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+      if (f[b]) sel.push_back(b);
+  }
+  (void)h;
+  return sel;
+}
+
+// ---------------------------------------------------------------------------------
+// stages
+// ---------------------------------------------------------------------------------
+static void search_dense(hx_index* h, const float* q_dev, int B, int prefix, int L, uint64_t* out_keys,
+                         int* out_cnt, hipStream_t st) {
+  HX_CHECK(B > 0, "B must be positive");
+  HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
+  if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  const MatrixRef m = pick_matrix(h, prefix);
+  const int bn = B <= 32 ? 32 : (B <= 64 ? 64 : 128);
+  const int Bpad = (int)round_up(B, bn);
+  float* qn = (float*)h->ws.get(WS_QN, (size_t)B * m.dpad * 4);
+  _Float16* qh = (_Float16*)h->ws.get(WS_QH, (size_t)Bpad * m.dpad * 2);
+  launch_prep_queries_f(q_dev, h->dim, B, Bpad, m.d, m.dpad, qn, qh, st);
+  int* fail = (int*)h->ws.get(WS_FAIL, (size_t)B * 4);
+  int* nfail = (int*)h->ws.get(WS_NFAIL, 4);
+  std::vector<int> sel;
+  if (m.m16) {
+    const Geometry g = geometry(L, true);
+    uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND, (size_t)B * g.C * 8);
+    uint64_t* cand2 = (uint64_t*)h->ws.get(WS_CAND2, (size_t)B * g.C * 8);
+    int* cnt = (int*)h->ws.get(WS_CNT, (size_t)B * 4);
+    int* ovf = (int*)h->ws.get(WS_OVF, (size_t)B * 4);
+    float* tau = (float*)h->ws.get(WS_TAU, (size_t)B * 4);
+    chunked_scan(h, KIND_F16, (const uint8_t*)m.m16, (const uint8_t*)qh, (int64_t)m.dpad * 2, B, bn, g,
+                 cand, cnt, ovf, tau, nullptr, st);
+    RescoreArgs r{};
+    r.kind = KIND_F32;
+    r.M = m.m32;
+    r.row_stride = m.dpad;
+    r.dim_pad = m.dpad;
+    r.Q = qn;
+    r.q_stride = m.dpad;
+    r.n_rows = h->n;
+    r.id_base = h->id_base;
+    r.cand = cand;
+    r.cnt = cnt;
+    r.stride = g.C;
+    r.B = B;
+    r.out = cand2;
+    launch_rescore_list(r, st);
+    launch_compact(cand2, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
+    HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
+    launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st);
+    sel = read_failures(h, fail, nfail, B, st);
+  } else {
+    sel.resize((size_t)B);
+    std::iota(sel.begin(), sel.end(), 0);
+  }
+  if (!sel.empty()) {
+    h->dense_fallbacks += (int64_t)sel.size();
+    exact_range_fallback(h, KIND_F32, m.m32, m.dpad, m.dpad, qn, m.dpad, nullptr, sel, L, out_keys,
+                         out_cnt, st);
+  }
+}
+
+static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* out_keys, int* out_cnt,
+                      hipStream_t st) {
+  HX_CHECK(B > 0, "B must be positive");
+  HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
+  if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  const int bn = B <= 32 ? 32 : (B <= 64 ? 64 : 128);
+  const int Bpad = (int)round_up(B, bn);
+  int8_t* q8 = (int8_t*)h->ws.get(WS_Q8, (size_t)Bpad * h->dim_pad8);
+  float* rq = (float*)h->ws.get(WS_RINVQ, (size_t)Bpad * 4);
+  launch_prep_queries_i8(q_dev, h->dim, B, Bpad, h->dim_pad8, q8, rq, st);
+  const Geometry g = geometry(L, false);
+  uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND, (size_t)B * g.C * 8);
+  int* cnt = (int*)h->ws.get(WS_CNT, (size_t)B * 4);
+  int* ovf = (int*)h->ws.get(WS_OVF, (size_t)B * 4);
+  float* tau = (float*)h->ws.get(WS_TAU, (size_t)B * 4);
+  int* fail = (int*)h->ws.get(WS_FAIL, (size_t)B * 4);
+  int* nfail = (int*)h->ws.get(WS_NFAIL, 4);
+  chunked_scan(h, KIND_I8, (const uint8_t*)h->q8, (const uint8_t*)q8, h->dim_pad8, B, bn, g, cand, cnt, ovf,
+               tau, rq, st);
+  launch_compact(cand, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
+  HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
+  launch_certify(cand, g.C, cnt, std::numeric_limits<int>::max(), out_keys, L, out_cnt, L, ovf, 0.f, B,
+                 fail, nfail, st);
+  std::vector<int> sel = read_failures(h, fail, nfail, B, st);
+  if (!sel.empty()) {
+    h->i8_fallbacks += (int64_t)sel.size();
+    exact_range_fallback(h, KIND_I8, h->q8, h->dim_pad8, h->dim_pad, q8, h->dim_pad8, rq, sel, L, out_keys,
+                         out_cnt, st);
+  }
+}
+
+static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
+                          int B, int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
+  HX_CHECK(B > 0, "B must be positive");
+  HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
+  finalize(h, st);
+  if (h->n_segments == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  int parts = (512 + B - 1) / B;
+  parts = std::min(parts, h->n_segments);
+  parts = std::min(parts, CAND_CAP / L);
+  parts = std::max(parts, 1);
+  uint64_t* pk = (uint64_t*)h->ws.get(WS_SP_PARTS, (size_t)B * parts * L * 8);
+  int* pc = (int*)h->ws.get(WS_SP_PCNT, (size_t)B * parts * 4);
+  SparseQueryArgs a{};
+  a.ix.doc_local = h->sp.doc_local;
+  a.ix.w = h->sp.w;
+  a.ix.table = h->sp.table;
+  a.ix.table_mask = h->sp.table_cap - 1;
+  a.ix.n_docs = h->sp_docs_built;
+  a.ix.n_segments = h->n_segments;
+  a.ix.id_base = h->id_base;
+  a.q_indptr = q_indptr;
+  a.q_idx = q_idx;
+  a.q_val = q_val;
+  a.B = B;
+  a.parts = parts;
+  a.limit = L;
+  a.out = pk;
+  a.out_cnt = pc;
+  launch_sparse_score(a, st);
+  launch_compact(pk, parts * L, nullptr, B, L, 0, out_keys, L, out_cnt, nullptr, parts * L, st);
+}
+
+static void rescore(hx_index* h, const float* q_dev, int B, int prefix, const uint64_t* cand, int cstride,
+                    const int* ccnt, int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
+  HX_CHECK(B > 0, "B must be positive");
+  HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
+  HX_CHECK(cstride >= 1 && cstride <= CAND_CAP, "candidate stride out of range");
+  if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  const MatrixRef m = pick_matrix(h, prefix);
+  float* qn = (float*)h->ws.get(WS_QN, (size_t)B * m.dpad * 4);
+  launch_prep_queries_f(q_dev, h->dim, B, B, m.d, m.dpad, qn, nullptr, st);
+  uint64_t* tmp = (uint64_t*)h->ws.get(WS_RS_TMP, (size_t)B * cstride * 8);
+  RescoreArgs r{};
+  r.kind = KIND_F32;
+  r.M = m.m32;
+  r.row_stride = m.dpad;
+  r.dim_pad = m.dpad;
+  r.Q = qn;
+  r.q_stride = m.dpad;
+  r.n_rows = h->n;
+  r.id_base = h->id_base;
+  r.cand = cand;
+  r.cnt = ccnt;
+  r.stride = cstride;
+  r.B = B;
+  r.out = tmp;
+  launch_rescore_list(r, st);
+  launch_compact(tmp, cstride, ccnt, B, std::min(L, cstride), 1, out_keys, L, out_cnt, nullptr, cstride, st);
+}
+
+static void rrf(hx_index* h, const uint64_t* a, int as, const int* ac, const uint64_t* b, int bs,
+                const int* bc, int B, float k, int base, int limit, uint64_t* out_keys, int* out_cnt,
+                hipStream_t st, Workspace& ws) {
+  (void)h;
+  HX_CHECK(limit >= 1 && limit <= MAX_LIMIT, "rrf limit out of range");
+  HX_CHECK(as + bs <= CAND_CAP, "rrf lists too long");
+  uint64_t* tmp = (uint64_t*)ws.get(WS_RRF_TMP, (size_t)B * (as + bs) * 8);
+  int* tcnt = (int*)ws.get(WS_MISC, (size_t)B * 4);
+  launch_rrf(a, as, ac, b, bs, bc, B, k, base, std::min(limit, as + bs), tmp, tcnt, st);
+  // copy the first `limit` slots of each fused row
+  launch_compact(tmp, as + bs, tcnt, B, std::min(limit, as + bs), 0, out_keys, limit, out_cnt, nullptr,
+                 as + bs, st);
+}
+
+static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix,
+                             const float* qv, int B, const hx_params* p, uint64_t* out_keys, int* out_cnt,
+                             hipStream_t st) {
+  Workspace& w = h->ws;
+  auto keys = [&](int slot, int L) { return (uint64_t*)w.get(slot, (size_t)B * L * 8); };
+  auto cnts = [&](int slot) { return (int*)w.get(slot, (size_t)B * 4); };
+  const float rk = p->rrf_k;
+  if (p->mode == HX_MODE_H1) {
+    uint64_t* D = keys(WS_T_A, p->dense_limit);
+    int* Dc = cnts(WS_T_ACNT);
+    uint64_t* S = keys(WS_T_B, p->sparse_limit);
+    int* Sc = cnts(WS_T_BCNT);
+    search_dense(h, qd, B, 0, p->dense_limit, D, Dc, st);
+    search_sparse(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+    rrf(h, D, p->dense_limit, Dc, S, p->sparse_limit, Sc, B, rk, p->rrf_rank_base, p->final_limit, out_keys,
+        out_cnt, st, w);
+    return;
+  }
+  // --- matryoshka cascade (qdrant_handler.py:305-330)
+  const int lim[3] = {p->matryoshka_64_limit, p->matryoshka_128_limit, p->matryoshka_256_limit};
+  uint64_t* A = keys(WS_T_A, p->dense_limit);
+  int* Ac = cnts(WS_T_ACNT);
+  if (h->n_pre == 0) {
+    search_dense(h, qd, B, 0, p->dense_limit, A, Ac, st);
+  } else {
+    uint64_t* c0 = keys(WS_T_C, lim[0]);
+    int* c0c = cnts(WS_T_CCNT);
+    search_dense(h, qd, B, h->psize[0], lim[0], c0, c0c, st);
+    uint64_t* cur = c0;
+    int* curc = c0c;
+    int curL = lim[0];
+    const int slots[2][2] = {{WS_T_D, WS_T_DCNT}, {WS_T_E, WS_T_ECNT}};
+    for (int s = 1; s < h->n_pre; ++s) {
+      uint64_t* nx = keys(slots[s - 1][0], lim[s]);
+      int* nxc = cnts(slots[s - 1][1]);
+      rescore(h, qd, B, h->psize[s], cur, curL, curc, lim[s], nx, nxc, st);
+      cur = nx;
+      curc = nxc;
+      curL = lim[s];
+    }
+    rescore(h, qd, B, 0, cur, curL, curc, p->dense_limit, A, Ac, st);
+  }
+  // --- quantized -> dense refinement (:333-344)
+  uint64_t* Qc = keys(WS_T_C, p->quantized_limit);
+  int* Qcc = cnts(WS_T_CCNT);
+  search_i8(h, qd, B, p->quantized_limit, Qc, Qcc, st);
+  uint64_t* Dq = keys(WS_T_D, p->dense_limit);
+  int* Dqc = cnts(WS_T_DCNT);
+  rescore(h, qd, B, 0, Qc, p->quantized_limit, Qcc, p->dense_limit, Dq, Dqc, st);
+  // --- sparse (:347-354)
+  uint64_t* S = keys(WS_T_B, p->sparse_limit);
+  int* Sc = cnts(WS_T_BCNT);
+  search_sparse(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+  // --- RRF (:357-360)
+  uint64_t* R = keys(WS_T_E, p->rrf_limit);
+  int* Rc = cnts(WS_T_ECNT);
+  rrf(h, Dq, p->dense_limit, Dqc, S, p->sparse_limit, Sc, B, rk, p->rrf_rank_base, p->rrf_limit, R, Rc, st, w);
+  // --- root: union re-scored by dense cosine (:363-372)
+  const int us = p->dense_limit + p->rrf_limit;
+  uint64_t* U = keys(WS_T_F, us);
+  launch_concat(A, p->dense_limit, Ac, R, p->rrf_limit, Rc, B, U, st);
+  rescore(h, qd, B, 0, U, us, nullptr, p->final_limit, out_keys, out_cnt, st);
+}
+
+static void check_params(const hx_params* p) {
+  HX_CHECK(p != nullptr, "params is NULL");
+  HX_CHECK(p->mode == HX_MODE_TREE || p->mode == HX_MODE_H1, "unknown mode");
+  auto ok = [](int v) { return v >= 1 && v <= MAX_LIMIT; };
+  HX_CHECK(ok(p->dense_limit) && ok(p->sparse_limit) && ok(p->final_limit), "limit out of range [1, 2048]");
+  if (p->mode == HX_MODE_TREE) {
+    HX_CHECK(ok(p->matryoshka_64_limit) && ok(p->matryoshka_128_limit) && ok(p->matryoshka_256_limit) &&
+                 ok(p->quantized_limit) && ok(p->rrf_limit),
+             "limit out of range [1, 2048]");
+  }
+}
+
+}  // namespace hx
+
+// =================================================================================
+// C ABI
+// =================================================================================
+#define HX_TRY try {
+#define HX_CATCH                                  \
+  }                                               \
+  catch (const std::exception& e) {               \
+    hx::set_last_error(e.what());                 \
+    return 1;                                     \
+  }                                               \
+  catch (...) {                                   \
+    hx::set_last_error("unknown error");          \
+    return 1;                                     \
+  }                                               \
+  return 0;
+
+extern "C" {
+
+const char* hx_last_error(void) { return hx::g_last_error.c_str(); }
+int hx_abi_version(void) { return HX_ABI_VERSION; }
+
+int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t device, int64_t id_base,
+              hx_index** out) {
+  HX_TRY
+  HX_CHECK(out != nullptr, "out is NULL");
+  HX_CHECK(dim >= 1 && dim <= 4096, "dim out of range [1, 4096]");
+  HX_CHECK(n_msizes >= 0 && n_msizes <= 3, "at most 3 matryoshka sizes");
+  HX_CHECK(id_base >= 0 && id_base < 0xFFFFFFFFll, "id_base out of range");
+  int ndev = 0;
+  HX_HIP(hipGetDeviceCount(&ndev));
+  HX_CHECK(ndev > 0, "no HIP device: libhx has no CPU path");
+  HX_CHECK(device >= 0 && device < ndev, "bad device ordinal");
+  auto* h = new hx_index();
+  h->dim = dim;
+  h->dim_pad = (int)round_up(dim, 64);
+  h->dim_pad8 = (int)round_up(dim, 128);
+  h->device = device;
+  h->id_base = id_base;
+  h->n_pre = n_msizes;
+  for (int i = 0; i < n_msizes; ++i) {
+    if (!(msizes[i] % 64 == 0 && msizes[i] >= 64 && msizes[i] <= dim && (i == 0 || msizes[i] > msizes[i - 1]))) {
+      delete h;
+      throw Error("matryoshka sizes must be ascending multiples of 64, <= dim");
+    }
+    h->psize[i] = msizes[i];
+  }
+  h->set_device();
+  *out = h;
+  HX_CATCH
+}
+
+int hx_destroy(hx_index* h) {
+  HX_TRY
+  if (!h) return 0;
+  h->set_device();
+  (void)hipDeviceSynchronize();
+  free_sparse_index(h);
+  void* ptrs[] = {h->dense, h->dense_h, h->q8, h->q8_rinv, h->pre[0], h->pre[1], h->pre[2], h->pre_h0,
+                  h->sp_indptr, h->sp_idx, h->sp_val};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  h->ws.release();
+  delete h;
+  HX_CATCH
+}
+
+int hx_reserve(hx_index* h, int64_t n_rows, int64_t nnz) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  h->set_device();
+  reserve_rows(h, n_rows);
+  if (nnz > 0) reserve_sparse(h, n_rows, nnz);
+  HX_CATCH
+}
+
+int hx_add_dense(hx_index* h, const float* rows_host, int64_t n) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  HX_CHECK(n >= 0, "n < 0");
+  if (n == 0) return 0;
+  HX_CHECK(rows_host, "rows is NULL");
+  HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
+  h->set_device();
+  reserve_rows(h, h->n + n);
+  const int64_t CH = 65536;
+  float* raw = (float*)h->ws.get(WS_RAW, (size_t)std::min(n, CH) * h->dim * 4);
+  for (int64_t r0 = 0; r0 < n; r0 += CH) {
+    const int64_t m = std::min(CH, n - r0);
+    HX_HIP(hipMemcpy(raw, rows_host + r0 * h->dim, (size_t)m * h->dim * 4, hipMemcpyHostToDevice));
+    prep_rows_device(h, raw, m, nullptr);
+    HX_HIP(hipStreamSynchronize(nullptr));
+    h->n += m;
+  }
+  HX_CATCH
+}
+
+int hx_add_sparse(hx_index* h, const int64_t* indptr, const int32_t* idx, const float* val, int64_t n) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  HX_CHECK(n >= 0, "n < 0");
+  if (n == 0) return 0;
+  HX_CHECK(indptr, "indptr is NULL");
+  HX_CHECK(indptr[0] == 0, "indptr[0] must be 0");
+  const int64_t nnz = indptr[n];
+  HX_CHECK(nnz >= 0, "negative nnz");
+  HX_CHECK(nnz == 0 || (idx && val), "idx/val is NULL");
+  std::vector<int32_t> tmp;
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t b = indptr[r], e = indptr[r + 1];
+    HX_CHECK(e >= b && e <= nnz, "indptr not monotone");
+    tmp.assign(idx + b, idx + e);
+    std::sort(tmp.begin(), tmp.end());
+    for (size_t i = 0; i < tmp.size(); ++i) {
+      HX_CHECK(tmp[i] >= 0, "sparse index out of range [0, 2^31)");
+      HX_CHECK(i == 0 || tmp[i] != tmp[i - 1], "sparse indices must be unique within a vector");
+    }
+  }
+  h->set_device();
+  HX_CHECK(h->nnz + nnz < 0xFFFFFFFFll, "nnz per shard must stay below 2^32");
+  reserve_sparse(h, h->sp_rows + n, h->nnz + nnz);
+  std::vector<int64_t> ip((size_t)n);
+  for (int64_t r = 0; r < n; ++r) ip[(size_t)r] = h->nnz + indptr[r + 1];
+  if (h->sp_rows == 0) {
+    const int64_t zero = 0;
+    HX_HIP(hipMemcpy(h->sp_indptr, &zero, 8, hipMemcpyHostToDevice));
+  }
+  HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows + 1, ip.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+  if (nnz) {
+    HX_HIP(hipMemcpy(h->sp_idx + h->nnz, idx, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    HX_HIP(hipMemcpy(h->sp_val + h->nnz, val, (size_t)nnz * 4, hipMemcpyHostToDevice));
+  }
+  h->sp_rows += n;
+  h->nnz += nnz;
+  h->sparse_stale = true;
+  HX_CATCH
+}
+
+int hx_finalize(hx_index* h) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  h->set_device();
+  finalize(h, nullptr);
+  HX_CATCH
+}
+
+int hx_count(hx_index* h, int64_t* n_rows) {
+  HX_TRY
+  HX_CHECK(h && n_rows, "NULL argument");
+  *n_rows = h->n;
+  HX_CATCH
+}
+int hx_nnz(hx_index* h, int64_t* nnz) {
+  HX_TRY
+  HX_CHECK(h && nnz, "NULL argument");
+  *nnz = h->nnz;
+  HX_CATCH
+}
+
+int hx_synth_fill(hx_index* h, int64_t n, uint32_t seed_dense, uint32_t seed_sparse, const uint32_t* cdf,
+                  int32_t V, const uint16_t* len_tab, int32_t with_sparse) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  HX_CHECK(n >= 0, "n < 0");
+  if (n == 0) return 0;
+  HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
+  h->set_device();
+  hipStream_t st = nullptr;
+  reserve_rows(h, h->n + n);
+  const int64_t row0 = h->n;
+  if (with_sparse) {
+    HX_CHECK(cdf && len_tab && V > 1, "sparse tables missing");
+    HX_CHECK(h->sp_rows == h->n, "synthetic sparse fill needs one sparse row per dense row so far");
+    uint32_t* dcdf = (uint32_t*)h->ws.get(WS_MISC, (size_t)V * 4 + 512);
+    uint16_t* dlen = (uint16_t*)((uint8_t*)dcdf + (size_t)V * 4);
+    HX_HIP(hipMemcpy(dcdf, cdf, (size_t)V * 4, hipMemcpyHostToDevice));
+    HX_HIP(hipMemcpy(dlen, len_tab, 512, hipMemcpyHostToDevice));
+    int64_t* per = (int64_t*)h->ws.get(WS_SYN_NNZ, (size_t)(n + 1) * 8 * 2);
+    int64_t* ip = per + (n + 1);
+    HX_HIP(hipMemsetAsync(per, 0, (size_t)(n + 1) * 8, st));
+    synth_sparse_count(h->id_base + row0, n, seed_sparse, dcdf, V, dlen, per, st);
+    exclusive_scan_i64(per, ip, n, st);
+    int64_t add = 0;
+    HX_HIP(hipMemcpy(&add, ip + n, 8, hipMemcpyDeviceToHost));
+    HX_CHECK(h->nnz + add < 0xFFFFFFFFll, "nnz per shard must stay below 2^32");
+    reserve_sparse(h, h->sp_rows + n, h->nnz + add);
+    synth_sparse_fill(h->id_base + row0, n, seed_sparse, dcdf, V, dlen, ip, h->sp_idx + h->nnz,
+                      h->sp_val + h->nnz, st);
+    // global indptr = base nnz + local
+    std::vector<int64_t> hip_((size_t)(n + 1));
+    HX_HIP(hipMemcpy(hip_.data(), ip, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+    for (auto& v : hip_) v += h->nnz;
+    HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows, hip_.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+    h->sp_rows += n;
+    h->nnz += add;
+    h->sparse_stale = true;
+  }
+  const int64_t CH = 65536;
+  float* raw = (float*)h->ws.get(WS_RAW, (size_t)std::min(n, CH) * h->dim * 4);
+  for (int64_t r0 = 0; r0 < n; r0 += CH) {
+    const int64_t m = std::min(CH, n - r0);
+    launch_synth_dense(raw, h->id_base + h->n, m, h->dim, seed_dense, st);
+    prep_rows_device(h, raw, m, st);
+    h->n += m;
+  }
+  HX_HIP(hipStreamSynchronize(st));
+  HX_CATCH
+}
+
+int hx_synth_queries_dense(int32_t dim, int64_t q0, int32_t B, uint32_t seed, float* q_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(q_dev && B > 0 && dim > 0, "bad argument");
+  launch_synth_dense(q_dev, q0, B, dim, seed, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_search_dense(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, int32_t limit,
+                    uint64_t* keys_dev, int32_t* counts_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && q_dev && keys_dev && counts_dev, "NULL argument");
+  h->set_device();
+  search_dense(h, q_dev, B, prefix, limit, keys_dev, counts_dev, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_search_i8(hx_index* h, const float* q_dev, int32_t B, int32_t limit, uint64_t* keys_dev,
+                 int32_t* counts_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && q_dev && keys_dev && counts_dev, "NULL argument");
+  h->set_device();
+  search_i8(h, q_dev, B, limit, keys_dev, counts_dev, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_search_sparse(hx_index* h, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
+                     const float* q_val_dev, int32_t B, int32_t max_terms, int32_t limit,
+                     uint64_t* keys_dev, int32_t* counts_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && q_indptr_dev && keys_dev && counts_dev, "NULL argument");
+  (void)max_terms;
+  h->set_device();
+  search_sparse(h, q_indptr_dev, q_idx_dev, q_val_dev, B, limit, keys_dev, counts_dev, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_rescore(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, const uint64_t* cand_keys_dev,
+               int32_t cand_stride, const int32_t* cand_counts_dev, int32_t limit, uint64_t* keys_dev,
+               int32_t* counts_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && q_dev && cand_keys_dev && keys_dev && counts_dev, "NULL argument");
+  h->set_device();
+  rescore(h, q_dev, B, prefix, cand_keys_dev, cand_stride, cand_counts_dev, limit, keys_dev, counts_dev,
+          (hipStream_t)stream);
+  HX_CATCH
+}
+
+static hx::Workspace& static_ws(int device) {
+  static std::map<int, hx::Workspace> w;
+  return w[device];
+}
+
+int hx_rrf(int32_t device, const uint64_t* a, int32_t as, const int32_t* ac, const uint64_t* b, int32_t bs,
+           const int32_t* bc, int32_t B, float rrf_k, int32_t rank_base, int32_t limit, uint64_t* keys_dev,
+           int32_t* counts_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(a && ac && b && bc && keys_dev && counts_dev && B > 0, "bad argument");
+  HX_HIP(hipSetDevice(device));
+  rrf(nullptr, a, as, ac, b, bs, bc, B, rrf_k, rank_base, limit, keys_dev, counts_dev, (hipStream_t)stream,
+      static_ws(device));
+  HX_CATCH
+}
+
+int hx_merge(int32_t device, const uint64_t* in_keys, int32_t stride, const int32_t* in_counts, int32_t B,
+             int32_t limit, int32_t dedupe, uint64_t* keys_dev, int32_t* counts_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(in_keys && keys_dev && counts_dev && B > 0, "bad argument");
+  HX_CHECK(stride >= 1 && stride <= CAND_CAP, "merge stride out of range [1, 8192]");
+  HX_CHECK(limit >= 1 && limit <= MAX_LIMIT, "limit out of range [1, 2048]");
+  HX_HIP(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  // compact cannot alias distinct strides: go through scratch
+  uint64_t* tmp = (uint64_t*)static_ws(device).get(WS_RS_TMP, (size_t)B * stride * 8);
+  HX_HIP(hipMemcpyAsync(tmp, in_keys, (size_t)B * stride * 8, hipMemcpyDeviceToDevice, st));
+  launch_compact(tmp, stride, in_counts, B, std::min(limit, stride), dedupe, keys_dev, limit, counts_dev,
+                 nullptr, stride, st);
+  HX_CATCH
+}
+
+int hx_unpack(int32_t device, const uint64_t* keys_dev, int64_t n, float* scores_dev, int64_t* ids_dev,
+              void* stream) {
+  HX_TRY
+  HX_CHECK(keys_dev && scores_dev && ids_dev, "NULL argument");
+  HX_HIP(hipSetDevice(device));
+  launch_unpack(keys_dev, n, scores_dev, ids_dev, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix,
+                        const float* qv, int32_t B, int32_t max_terms, const hx_params* p,
+                        uint64_t* keys_dev, int32_t* counts_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && qd && qip && keys_dev && counts_dev, "NULL argument");
+  (void)max_terms;
+  check_params(p);
+  h->set_device();
+  hybrid_query_dev(h, qd, qip, qix, qv, B, p, keys_dev, counts_dev, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_hybrid_query_host(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix,
+                         const float* qv, int32_t B, const hx_params* p, float* scores, int64_t* ids,
+                         int32_t* counts) {
+  HX_TRY
+  HX_CHECK(h && qd && qip && scores && ids && counts && B > 0, "bad argument");
+  check_params(p);
+  h->set_device();
+  hipStream_t st = nullptr;
+  const int64_t nnz = qip[B];
+  HX_CHECK(qip[0] == 0 && nnz >= 0, "bad query indptr");
+  // sort each query's terms by id (the spec's summation order), reject duplicates
+  std::vector<int32_t> six((size_t)nnz);
+  std::vector<float> sv((size_t)nnz);
+  std::vector<int> ord;
+  for (int b = 0; b < B; ++b) {
+    const int64_t s = qip[b], e = qip[b + 1];
+    HX_CHECK(e >= s && e <= nnz, "bad query indptr");
+    ord.resize((size_t)(e - s));
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return qix[s + x] < qix[s + y]; });
+    for (size_t i = 0; i < ord.size(); ++i) {
+      six[(size_t)s + i] = qix[s + ord[i]];
+      sv[(size_t)s + i] = qv[s + ord[i]];
+      HX_CHECK(six[(size_t)s + i] >= 0, "sparse index out of range");
+      HX_CHECK(i == 0 || six[(size_t)s + i] != six[(size_t)s + i - 1], "duplicate sparse index in query");
+    }
+  }
+  const int L = p->final_limit;
+  float* dq = (float*)h->ws.get(WS_H_QD, (size_t)B * h->dim * 4);
+  int64_t* dip = (int64_t*)h->ws.get(WS_H_QIP, (size_t)(B + 1) * 8);
+  int32_t* dix = (int32_t*)h->ws.get(WS_H_QIX, (size_t)std::max<int64_t>(nnz, 1) * 4);
+  float* dv = (float*)h->ws.get(WS_H_QV, (size_t)std::max<int64_t>(nnz, 1) * 4);
+  uint64_t* ok = (uint64_t*)h->ws.get(WS_H_OUT, (size_t)B * L * 8);
+  int* oc = (int*)h->ws.get(WS_H_OCNT, (size_t)B * 4);
+  float* osc = (float*)h->ws.get(WS_H_SC, (size_t)B * L * 4);
+  int64_t* oid = (int64_t*)h->ws.get(WS_H_ID, (size_t)B * L * 8);
+  HX_HIP(hipMemcpyAsync(dq, qd, (size_t)B * h->dim * 4, hipMemcpyHostToDevice, st));
+  HX_HIP(hipMemcpyAsync(dip, qip, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+  if (nnz) {
+    HX_HIP(hipMemcpyAsync(dix, six.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+    HX_HIP(hipMemcpyAsync(dv, sv.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+  }
+  hybrid_query_dev(h, dq, dip, dix, dv, B, p, ok, oc, st);
+  launch_unpack(ok, (int64_t)B * L, osc, oid, st);
+  HX_HIP(hipMemcpyAsync(scores, osc, (size_t)B * L * 4, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipMemcpyAsync(ids, oid, (size_t)B * L * 8, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipMemcpyAsync(counts, oc, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  HX_CATCH
+}
+
+int hx_get_stats(hx_index* h, hx_stats* out) {
+  HX_TRY
+  HX_CHECK(h && out, "NULL argument");
+  std::memset(out, 0, sizeof(*out));
+  out->n_rows = h->n;
+  out->nnz = h->nnz;
+  out->n_segments = h->n_segments;
+  out->n_groups = h->sp.n_groups;
+  out->hash_capacity = (int64_t)h->sp.table_cap;
+  out->bytes_dense_f32 = h->n * h->dim_pad * 4;
+  out->bytes_dense_f16 = h->n * h->dim_pad * 2;
+  out->bytes_i8 = h->n * h->dim_pad8;
+  int64_t bp = 0;
+  for (int p = 0; p < h->n_pre; ++p) bp += h->n * h->psize[p] * 4;
+  if (h->n_pre) bp += h->n * h->psize[0] * 2;
+  out->bytes_prefix = bp;
+  out->bytes_sparse = h->nnz * 6 + (int64_t)h->sp.table_cap * (int64_t)sizeof(SpHashEntry);
+  out->dense_fallback_queries = h->dense_fallbacks;
+  out->i8_fallback_queries = h->i8_fallbacks;
+  HX_CATCH
+}
+
+int hx_debug_row(hx_index* h, int32_t which, int64_t row, void* out_host) {
+  HX_TRY
+  HX_CHECK(h && out_host, "NULL argument");
+  HX_CHECK(row >= 0 && row < h->n, "row out of range");
+  h->set_device();
+  if (which == 0) {
+    HX_HIP(hipMemcpy(out_host, h->dense + row * h->dim_pad, (size_t)h->dim * 4, hipMemcpyDeviceToHost));
+  } else if (which >= 1 && which <= h->n_pre) {
+    const int p = which - 1;
+    HX_HIP(hipMemcpy(out_host, h->pre[p] + row * h->psize[p], (size_t)h->psize[p] * 4, hipMemcpyDeviceToHost));
+  } else if (which == 4) {
+    HX_HIP(hipMemcpy(out_host, h->q8 + row * h->dim_pad8, (size_t)h->dim, hipMemcpyDeviceToHost));
+  } else {
+    throw Error("bad `which`");
+  }
+  HX_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// Kernel argument blocks and host-side launch prototypes (libhx, gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hx {
+
+enum { KIND_F16 = 0, KIND_I8 = 1, KIND_F32 = 2 };
+
+// Rigorous bound on |fp16-scan score - spec score| for unit-norm rows and queries
+// (DESIGN.md "certificate"): input rounding 2*2^-11 + 2^-22, fp32 accumulation
+// (D+19)*2^-24 for D <= 4096, plus the subnormal-half terms; 1.25e-3 has > 10 %
+// slack over the sum for D <= 4096.
+constexpr float HX_EPS_F16 = 1.25e-3f;
+
+// ---- scan.hip ----------------------------------------------------------------
+struct ScanArgs {
+  const uint8_t* A;        // corpus matrix (fp16 or int8 rows), stride row_bytes
+  const uint8_t* Q;        // query matrix [nq_tiles*BN x row_bytes], zero-padded rows
+  int64_t row_bytes;       // multiple of 128
+  int64_t row_begin, row_end;  // local rows scanned by this launch
+  int B;                   // valid queries
+  int nq_tiles;
+  const float* tau;        // [B] append threshold (score >= tau passes)
+  uint64_t* cand;          // [B x cap] candidate keys
+  int* cnt;                // [B] appended so far (may exceed cap)
+  int* overflow;           // [B] set when an append was dropped
+  int cap;
+  int64_t id_base;
+  const float* rinv_x;     // i8: 1/||x|| per local row (padded)
+  const float* rinv_q;     // i8: 1/||q|| per query (padded)
+};
+void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st);
+
+// ---- select.hip --------------------------------------------------------------
+// Sort each query's buffer (first min(cnt, stride) keys) best-first, optionally drop
+// duplicate keys, keep `keep`; writes out_keys[b*out_stride + r] (may alias `keys`
+// when out_stride == stride), out_cnt[b], and tau[b] = score of the keep-th key when
+// the list is full, else -inf (tau may be NULL).  in_cnt NULL => all `stride` slots.
+void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int keep, int dedupe,
+                    uint64_t* out_keys, int out_stride, int* out_cnt, float* tau,
+                    int max_cnt_hint, hipStream_t st);
+
+// Exact spec score of listed candidates: out_keys[b*stride + i] = key(spec_dot(row, q_b), id)
+// for i < min(cnt[b], stride); ids outside [id_base, id_base+n) give key 0.
+struct RescoreArgs {
+  int kind;                // KIND_F32 (spec_dot over fp32 rows) or KIND_I8
+  const void* M;           // matrix base
+  int64_t row_stride;      // elements per row
+  int dim_pad;             // padded dim (multiple of 64)
+  const void* Q;           // prepared queries: f32 [B x dim_pad] or i8 [B x row_stride]
+  int64_t q_stride;
+  const float* rinv_x;     // i8 only
+  const float* rinv_q;     // i8 only
+  int64_t n_rows;
+  int64_t id_base;
+  const uint64_t* cand;    // [B x stride]
+  const int* cnt;          // [B] (NULL => stride)
+  int stride;
+  int B;
+  uint64_t* out;           // [B x stride]
+};
+void launch_rescore_list(const RescoreArgs& a, hipStream_t st);
+
+// Exact scores of ALL rows [row_begin,row_end) for the listed queries (fallback path):
+// out[qsel[f]*stride + slot0 + (row-row_begin)] = key.
+struct RangeArgs {
+  RescoreArgs r;           // cand/cnt/out/stride reused: out = buffer, stride = its stride
+  const int* qsel;         // [nsel] query indices
+  int nsel;
+  int64_t row_begin, row_end;
+  int slot0;
+};
+void launch_rescore_range(const RangeArgs& a, hipStream_t st);
+
+// fail[b] = overflow[b] || (approx_cnt[b] >= lprime && !(approx_Lprime_score + eps < exact_L_score))
+void launch_certify(const uint64_t* approx_keys, int approx_stride, const int* approx_cnt, int lprime,
+                    const uint64_t* exact_keys, int exact_stride, const int* exact_cnt, int L,
+                    const int* overflow, float eps, int B, int* fail, int* nfail, hipStream_t st);
+
+void launch_rrf(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride,
+                const int* b_cnt, int B, float k, int rank_base, int limit, uint64_t* out,
+                int* out_cnt, hipStream_t st);
+void launch_unpack(const uint64_t* keys, int64_t n, float* scores, int64_t* ids, hipStream_t st);
+// out[b*(sa+sb) ...] = a-list then b-list (empty slots 0)
+void launch_concat(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride,
+                   const int* b_cnt, int B, uint64_t* out, hipStream_t st);
+void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
+void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st);
+
+// ---- prep.hip ----------------------------------------------------------------
+// Derive the stored vectors of rows [0,n) of `raw` (fp32 [n x dim]):
+struct PrepRowsArgs {
+  const float* raw;        // [n x dim]
+  int dim, dim_pad;        // dim_pad = round_up(dim, 64)
+  int64_t n;
+  float* dense;            // [n x dim_pad] L2-normalised (zero padded)
+  _Float16* dense_h;       // [n x dim_pad]
+  int8_t* q8;              // [n x dim_pad8] trunc(127*x) of the RAW row
+  int dim_pad8;            // round_up(dim, 128)
+  float* q8_rinv;          // [n]
+  int n_prefix;
+  int psize[3];
+  float* pre[3];           // [n x psize] normalised prefixes of the RAW row
+  _Float16* pre_h0;        // fp16 copy of prefix 0 (may be NULL)
+};
+void launch_prep_rows(const PrepRowsArgs& a, hipStream_t st);
+void launch_synth_dense(float* raw, int64_t row0_global, int64_t n, int dim, uint32_t seed, hipStream_t st);
+
+// Prepare a query batch for one named vector: normalised fp32 [B x dpad] (+ fp16
+// zero-padded to Bpad rows) from raw q[:, :d]; or the int8 copy + rinv.
+void launch_prep_queries_f(const float* q_raw, int q_dim, int B, int Bpad, int d, int dpad,
+                           float* qn, _Float16* qh, hipStream_t st);
+void launch_prep_queries_i8(const float* q_raw, int q_dim, int B, int Bpad, int dpad8, int8_t* q8,
+                            float* rinv_q, hipStream_t st);
+
+// ---- sparse.hip --------------------------------------------------------------
+constexpr int SEG_DOCS = 8192;        // docs per index segment (LDS accumulator = 32 KiB)
+struct SpHashEntry {
+  uint64_t key;            // (segment << 31) | term ; ~0 = empty
+  uint32_t off, len;
+};
+struct SparseIndexView {
+  const uint16_t* doc_local;   // [nnz] segment-major, term-sorted postings
+  const float* w;              // [nnz]
+  const SpHashEntry* table;
+  uint64_t table_mask;
+  int64_t n_docs;
+  int n_segments;
+  int64_t id_base;
+};
+struct SparseQueryArgs {
+  SparseIndexView ix;
+  const int64_t* q_indptr;     // [B+1]
+  const int32_t* q_idx;        // ascending within a query
+  const float* q_val;
+  int B;
+  int parts;                   // blocks per query (each owns a contiguous segment range)
+  int limit;
+  uint64_t* out;               // [B x parts x limit] sorted best-first per (query, part)
+  int* out_cnt;                // [B x parts]
+};
+void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st);
+
+// ---- spbuild.hip -------------------------------------------------------------
+struct SparseBuildOut {
+  uint16_t* doc_local;
+  float* w;
+  SpHashEntry* table;
+  uint64_t table_cap;
+  int64_t n_groups;
+};
+// Build the segment-major inverted index from doc-major CSR on the device.
+void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,
+                        int64_t nnz, SparseBuildOut* out, hipStream_t st);
+// Synthetic docs (oracle synth_sparse_docs): two passes.
+void synth_sparse_count(int64_t doc0_global, int64_t n, uint32_t seed, const uint32_t* cdf, int V,
+                        const uint16_t* len_tab, int64_t* nnz_per_doc, hipStream_t st);
+void synth_sparse_fill(int64_t doc0_global, int64_t n, uint32_t seed, const uint32_t* cdf, int V,
+                       const uint16_t* len_tab, const int64_t* indptr, int32_t* idx, float* val,
+                       hipStream_t st);
+void exclusive_scan_i64(const int64_t* in, int64_t* out, int64_t n, hipStream_t st);  // out[n] = total
+
+}  // namespace hx

@@ -1,0 +1,254 @@
+// K3/K4/K5 -- whole-collection scan: S = X . Q^T on the matrix cores, fused with a
+// threshold filter that appends (score, id) keys to per-query candidate buffers.
+//
+// Mirrors Prefetch(query=..., using="dense"|"matryoshka_*"|"quantized", limit=...)
+// of the reference (app/core/vector_store/qdrant/qdrant_handler.py:311-315,
+// 327-329, 335-339): "rank the whole collection by cosine".  Two element kinds
+// share one byte geometry (128 B of a row per k-step):
+//   KIND_F16: fp16 copies of the L2-normalised rows, v_mfma_f32_32x32x16_f16.
+//             Scores are APPROXIMATE (|err| <= HX_EPS_F16); the caller re-scores
+//             the survivors exactly and certifies the result (engine.cpp).
+//   KIND_I8 : the reference's trunc(127*x) copy, v_mfma_i32_32x32x32_i8; the
+//             integer dot is exact and the score (f32(dot)*rinv_x)*rinv_q is the
+//             oracle's arithmetic bit for bit.
+//
+// Layout: corpus rows are the MFMA A operand (M), queries the B operand (N), so a
+// lane of the 32x32 accumulator owns ONE query (col = lane & 31) and 16 corpus
+// rows: the per-query threshold is one register per tile.
+//
+// Staging: global_load_lds (16 B/lane, 1 KiB per wave-instruction = 8 rows x
+// 128 B) into an NSTAGE ring; the LDS image is lane-linear, the 16-B slot XOR
+// swizzle ((row>>1)&7) is applied on the SOURCE address and again on the
+// ds_read_b128 address, so every 16-lane read group hits 16 distinct bank slots.
+#include "hx_common.hpp"
+#include "kernels.hpp"
+
+namespace hx {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KIND, int BN, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
+  constexpr int BM = 128;
+  constexpr int WN = (BN >= 64) ? 2 : 1;
+  constexpr int WM = 4 / WN;
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_LPW = BM / 8 / 4;  // 1-KiB pieces per wave
+  constexpr int B_LPW = BN / 8 / 4;
+  constexpr int LPW = A_LPW + B_LPW;
+  static_assert(B_LPW >= 1, "BN >= 32");
+
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int KT = (int)(a.row_bytes >> 7);
+  const int64_t n_rows = a.row_end - a.row_begin;
+  const int n_row_tiles = (int)((n_rows + BM - 1) / BM);
+  const int nq = a.nq_tiles;
+
+  // XCD-aware tile walk: blocks with equal (blockIdx % 8) share an XCD (L2); XCD x
+  // owns row tiles == x (mod 8) and walks them with the query tile fastest, so the
+  // nq blocks that need one corpus tile run together on one L2.
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7;
+  const int per_xcd = G >> 3;
+  const int my_rt = (n_row_tiles - xcd + 7) >> 3;         // row tiles owned by this XCD
+  const int items_x = my_rt * nq;  // < 2^31: launch_scan bounds rows per launch
+  const int i0 = blockIdx.x >> 3;
+  if (i0 >= items_x) return;
+  const int my_items = (items_x - i0 + per_xcd - 1) / per_xcd;
+  const int64_t total_steps = (int64_t)my_items * KT;
+
+  // ---- load cursor -----------------------------------------------------------
+  int lj = i0;
+  int l_kt = 0;
+  int l_rt = (int)(lj / nq) * 8 + xcd, l_qt = (int)(lj % nq);
+  int64_t l_step = 0;
+
+  auto issue_load = [&]() {
+    const int st = (int)(l_step % NSTAGE);
+    uint8_t* sbase = lds + st * STAGE;
+    const int rin = lane >> 3, pslot = lane & 7;
+#pragma unroll
+    for (int c = 0; c < A_LPW; ++c) {
+      const int piece = wave + 4 * c;
+      const int trow = piece * 8 + rin;
+      int64_t grow = a.row_begin + (int64_t)l_rt * BM + trow;
+      grow = grow < a.row_end ? grow : a.row_end - 1;
+      const int lslot = pslot ^ ((trow >> 1) & 7);
+      const uint8_t* src = a.A + grow * a.row_bytes + ((int64_t)l_kt << 7) + (lslot << 4);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sbase + piece * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < B_LPW; ++c) {
+      const int piece = wave + 4 * c;
+      const int trow = piece * 8 + rin;
+      const int64_t qrow = (int64_t)l_qt * BN + trow;
+      const int lslot = pslot ^ ((trow >> 1) & 7);
+      const uint8_t* src = a.Q + qrow * a.row_bytes + ((int64_t)l_kt << 7) + (lslot << 4);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sbase + A_BYTES + piece * 1024), 16, 0, 0);
+    }
+    ++l_step;
+    if (++l_kt == KT) {
+      l_kt = 0;
+      lj += per_xcd;
+      l_rt = (int)(lj / nq) * 8 + xcd;
+      l_qt = (int)(lj % nq);
+    }
+  };
+
+  // ---- accumulators -----------------------------------------------------------
+  using acc_t = typename std::conditional<KIND == KIND_F16, f32x16, i32x16>::type;
+  acc_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+
+  // prologue: NSTAGE-1 steps in flight
+#pragma unroll
+  for (int p = 0; p < NSTAGE - 1; ++p)
+    if (l_step < total_steps) issue_load();
+
+  int cj = i0;
+  int c_kt = 0;
+  for (int64_t s = 0; s < total_steps; ++s) {
+    // retire the loads of step s (all but the youngest NSTAGE-2 groups)
+    if (s + NSTAGE - 2 < total_steps) {
+      wait_vmcnt<LPW*(NSTAGE - 2)>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // loads(s) of every wave landed; compute(s-1) done everywhere
+    if (l_step < total_steps) issue_load();  // into the stage compute(s-1) just released
+
+    const uint8_t* As = lds + (int)(s % NSTAGE) * STAGE;
+    const uint8_t* Bs = As + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      half8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + r;
+        af[i] = *(const half8*)(As + row * 128 + ((((kk << 1) | h) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + r;
+        bf[j] = *(const half8*)(Bs + row * 128 + ((((kk << 1) | h) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (KIND == KIND_F16) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                __builtin_bit_cast(i32x4, af[i]), __builtin_bit_cast(i32x4, bf[j]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+
+    if (++c_kt == KT) {
+      // ---- epilogue: threshold filter + append ----------------------------------
+      c_kt = 0;
+      const int rt = (int)(cj / nq) * 8 + xcd, qt = (int)(cj % nq);
+      cj += per_xcd;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int q = qt * BN + wn * (TN * 32) + j * 32 + r;
+        const bool qok = q < a.B;
+        const float tau = qok ? a.tau[q] : __builtin_inff();
+        float rq = 0.f;
+        if constexpr (KIND == KIND_I8) rq = qok ? a.rinv_q[q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int64_t row0 = a.row_begin + (int64_t)rt * BM + wm * (TM * 32) + i * 32 + 4 * h;
+          float sc[16];
+          if constexpr (KIND == KIND_F16) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[e] = acc[i][j][e];
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              // rows row0+8g .. +3 ; rinv_x is padded past n_rows so this never faults
+              const float4 rx = *(const float4*)(a.rinv_x + row0 + 8 * g);
+              sc[4 * g + 0] = ((float)acc[i][j][4 * g + 0] * rx.x) * rq;
+              sc[4 * g + 1] = ((float)acc[i][j][4 * g + 1] * rx.y) * rq;
+              sc[4 * g + 2] = ((float)acc[i][j][4 * g + 2] * rx.z) * rq;
+              sc[4 * g + 3] = ((float)acc[i][j][4 * g + 3] * rx.w) * rq;
+            }
+          }
+          bool hit = false;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) hit |= (sc[e] >= tau);
+          if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+              if (sc[e] >= tau && row < a.row_end) {
+                const int pos = atomicAdd(a.cnt + q, 1);
+                if (pos < a.cap)
+                  a.cand[(int64_t)q * a.cap + pos] = make_key(sc[e], (uint32_t)(a.id_base + row));
+                else
+                  a.overflow[q] = 1;
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+        }
+      }
+    }
+  }
+}
+
+template <int KIND, int BN, int NSTAGE>
+static void launch(const ScanArgs& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((k_scan<KIND, BN, NSTAGE>), dim3(grid), dim3(256), 0, st, a);
+}
+
+void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st) {
+  const int64_t n_rows = a.row_end - a.row_begin;
+  if (n_rows <= 0 || a.B <= 0) return;
+  HX_CHECK((a.row_bytes & 127) == 0, "scan: row_bytes must be a multiple of 128");
+  const int64_t tiles = (n_rows + 127) / 128 * a.nq_tiles;
+  int64_t g = tiles < 512 ? tiles : 512;
+  g = (g + 7) / 8 * 8;  // whole XCD groups; blocks without items exit at once
+  const int grid = (int)g;
+  if (kind == KIND_F16) {
+    if (bn == 128) launch<KIND_F16, 128, 2>(a, grid, st);
+    else if (bn == 64) launch<KIND_F16, 64, 3>(a, grid, st);
+    else launch<KIND_F16, 32, 3>(a, grid, st);
+  } else {
+    if (bn == 128) launch<KIND_I8, 128, 2>(a, grid, st);
+    else if (bn == 64) launch<KIND_I8, 64, 3>(a, grid, st);
+    else launch<KIND_I8, 32, 3>(a, grid, st);
+  }
+  HX_HIP(hipGetLastError());
+}
+
+}  // namespace hx

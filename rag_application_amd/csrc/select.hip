@@ -1,0 +1,320 @@
+// Candidate-list kernels: exact re-scoring (K6), top-L compaction, certificate,
+// reciprocal-rank fusion (K8), key packing.  All rankings use the 64-bit key whose
+// descending order is (score desc, id asc) -- oracle/oracle.py order_key.
+#include "hx_common.hpp"
+#include "kernels.hpp"
+
+namespace hx {
+
+// ---------------------------------------------------------------------------------
+// compaction: bitonic sort (descending) of <= 8192 keys in LDS, optional dedupe
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ keys, int stride,
+                                                 const int* __restrict__ in_cnt, int P, int keep,
+                                                 int dedupe, uint64_t* out_keys, int out_stride,
+                                                 int* out_cnt, float* tau) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint64_t* sk = (uint64_t*)smem;
+  __shared__ int part[256];
+  __shared__ uint64_t s_kth;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int n = in_cnt ? in_cnt[b] : stride;
+  n = n < stride ? n : stride;
+  n = n < P ? n : P;
+  for (int i = tid; i < P; i += 256) sk[i] = i < n ? keys[(int64_t)b * stride + i] : 0ull;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t x = sk[i], y = sk[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) {
+            sk[i] = y;
+            sk[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // flags + block scan (each thread owns P/256 consecutive slots; P >= 256)
+  const int per = P >> 8;
+  const int base = tid * per;
+  int c = 0;
+  for (int e = 0; e < per; ++e) {
+    const int i = base + e;
+    const uint64_t x = sk[i];
+    const bool f = x != 0ull && (!dedupe || i == 0 || x != sk[i - 1]);
+    c += f;
+  }
+  part[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const int total = part[255];
+  int pos = part[tid] - c;
+  uint64_t* o = out_keys + (int64_t)b * out_stride;
+  // read everything we need before any (possibly aliasing) write: it is all in LDS.
+  if (tid == 0) s_kth = 0ull;
+  __syncthreads();
+  for (int e = 0; e < per; ++e) {
+    const int i = base + e;
+    const uint64_t x = sk[i];
+    const bool f = x != 0ull && (!dedupe || i == 0 || x != sk[i - 1]);
+    if (f) {
+      if (pos < keep) o[pos] = x;
+      if (pos == keep - 1) s_kth = x;
+      ++pos;
+    }
+  }
+  const int kept = total < keep ? total : keep;
+  for (int i = kept + tid; i < out_stride; i += 256) o[i] = 0ull;  // empty slots are 0
+  __syncthreads();
+  if (tid == 0) {
+    out_cnt[b] = kept;
+    if (tau) tau[b] = (total >= keep && keep > 0) ? key_score(s_kth) : -__builtin_inff();
+  }
+}
+
+void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int keep, int dedupe,
+                    uint64_t* out_keys, int out_stride, int* out_cnt, float* tau, int max_cnt_hint,
+                    hipStream_t st) {
+  if (B <= 0) return;
+  int m = max_cnt_hint < stride ? max_cnt_hint : stride;
+  int P = next_pow2(m < 256 ? 256 : m);
+  HX_CHECK(P <= CAND_CAP, "compact: list longer than CAND_CAP");
+  HX_CHECK(keep <= out_stride, "compact: keep > out_stride");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HX_HIP(hipFuncSetAttribute((const void*)k_compact, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               CAND_CAP * 8));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_compact, dim3(B), dim3(256), (size_t)P * 8, st, keys, stride, in_cnt, P, keep,
+                     dedupe, out_keys, out_stride, out_cnt, tau);
+  HX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// spec arithmetic on one wave (oracle.spec_dot / i8_scores)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_spec_dot(const float* __restrict__ x, const float* __restrict__ q,
+                                               int dim_pad, int lane) {
+  float p = 0.0f;
+  for (int j = 0; j < dim_pad; j += 64) p = __fadd_rn(p, __fmul_rn(x[j + lane], q[j + lane]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) p = __fadd_rn(p, __shfl_down(p, off, 64));
+  return __fadd_rn(p, 0.0f);  // lane 0 holds the result
+}
+
+__device__ __forceinline__ int wave_i8_dot(const int8_t* __restrict__ x, const int8_t* __restrict__ q,
+                                           int dim_pad8, int lane) {
+  int acc = 0;
+  for (int j = lane * 4; j < dim_pad8; j += 256) {
+    const int xa = *(const int*)(x + j), qa = *(const int*)(q + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += (int)(int8_t)(xa >> (8 * e)) * (int)(int8_t)(qa >> (8 * e));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+  return acc;
+}
+
+__device__ __forceinline__ uint64_t exact_key(const RescoreArgs& a, int b, int64_t local, int lane) {
+  float s;
+  if (a.kind == KIND_F32) {
+    const float* x = (const float*)a.M + local * a.row_stride;
+    const float* q = (const float*)a.Q + (int64_t)b * a.q_stride;
+    s = wave_spec_dot(x, q, a.dim_pad, lane);
+  } else {
+    const int8_t* x = (const int8_t*)a.M + local * a.row_stride;
+    const int8_t* q = (const int8_t*)a.Q + (int64_t)b * a.q_stride;
+    const int d = wave_i8_dot(x, q, (int)a.row_stride, lane);
+    s = __fmul_rn(__fmul_rn((float)d, a.rinv_x[local]), a.rinv_q[b]);
+  }
+  return make_key(s, (uint32_t)(a.id_base + local));
+}
+
+__global__ __launch_bounds__(256) void k_rescore_list(RescoreArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (i >= a.stride) return;
+  int n = a.cnt ? a.cnt[b] : a.stride;
+  n = n < a.stride ? n : a.stride;
+  uint64_t out = 0ull;
+  if (i < n) {
+    const uint64_t ck = a.cand[(int64_t)b * a.stride + i];
+    if (ck != 0ull) {
+      const int64_t local = (int64_t)key_id(ck) - a.id_base;
+      if (local >= 0 && local < a.n_rows) out = exact_key(a, b, local, lane);
+    }
+  }
+  if (lane == 0) a.out[(int64_t)b * a.stride + i] = out;
+}
+
+void launch_rescore_list(const RescoreArgs& a, hipStream_t st) {
+  if (a.B <= 0 || a.stride <= 0) return;
+  hipLaunchKernelGGL(k_rescore_list, dim3((a.stride + 3) / 4, a.B), dim3(256), 0, st, a);
+  HX_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_rescore_range(RangeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = a.row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.row_end) return;
+  const int b = a.qsel[blockIdx.y];
+  const uint64_t k = exact_key(a.r, b, row, lane);
+  if (lane == 0) a.r.out[(int64_t)b * a.r.stride + a.slot0 + (row - a.row_begin)] = k;
+}
+
+void launch_rescore_range(const RangeArgs& a, hipStream_t st) {
+  const int64_t n = a.row_end - a.row_begin;
+  if (n <= 0 || a.nsel <= 0) return;
+  hipLaunchKernelGGL(k_rescore_range, dim3((unsigned)((n + 3) / 4), a.nsel), dim3(256), 0, st, a);
+  HX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// certificate: nothing outside the candidate set can reach the exact L-th score
+// ---------------------------------------------------------------------------------
+__global__ void k_certify(const uint64_t* approx_keys, int approx_stride, const int* approx_cnt,
+                          int lprime, const uint64_t* exact_keys, int exact_stride,
+                          const int* exact_cnt, int L, const int* overflow, float eps, int B, int* fail,
+                          int* nfail) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  bool bad = overflow[b] != 0;
+  if (!bad && approx_cnt[b] >= lprime) {
+    // candidate list is full: rows outside it have approx score <= m
+    const float m = key_score(approx_keys[(int64_t)b * approx_stride + lprime - 1]);
+    const int ec = exact_cnt[b];
+    if (ec < L) {
+      bad = true;  // cannot happen (lprime > L distinct rows), be safe
+    } else {
+      const float eL = key_score(exact_keys[(int64_t)b * exact_stride + L - 1]);
+      bad = !(__fadd_rn(m, eps) < eL);
+    }
+  }
+  fail[b] = bad ? 1 : 0;
+  if (bad) atomicAdd(nfail, 1);
+}
+
+void launch_certify(const uint64_t* approx_keys, int approx_stride, const int* approx_cnt, int lprime,
+                    const uint64_t* exact_keys, int exact_stride, const int* exact_cnt, int L,
+                    const int* overflow, float eps, int B, int* fail, int* nfail, hipStream_t st) {
+  hipLaunchKernelGGL(k_certify, dim3((B + 255) / 256), dim3(256), 0, st, approx_keys, approx_stride,
+                     approx_cnt, lprime, exact_keys, exact_stride, exact_cnt, L, overflow, eps, B, fail,
+                     nfail);
+  HX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// reciprocal-rank fusion of two ranked lists -> unsorted fused keys (then compact)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rrf(const uint64_t* a, int a_stride, const int* a_cnt,
+                                             const uint64_t* b, int b_stride, const int* b_cnt, float k,
+                                             int rank_base, uint64_t* out) {
+  const int q = blockIdx.x, tid = threadIdx.x;
+  int na = a_cnt[q], nb = b_cnt[q];
+  na = na < a_stride ? na : a_stride;
+  nb = nb < b_stride ? nb : b_stride;
+  const uint64_t* la = a + (int64_t)q * a_stride;
+  const uint64_t* lb = b + (int64_t)q * b_stride;
+  uint64_t* o = out + (int64_t)q * (a_stride + b_stride);
+  for (int i = tid; i < a_stride; i += 256) {
+    uint64_t r = 0ull;
+    if (i < na) {
+      const uint32_t id = key_id(la[i]);
+      float s = __fadd_rn(0.0f, __fdiv_rn(1.0f, __fadd_rn((float)(i + rank_base), k)));
+      for (int j = 0; j < nb; ++j)
+        if (key_id(lb[j]) == id) {
+          s = __fadd_rn(s, __fdiv_rn(1.0f, __fadd_rn((float)(j + rank_base), k)));
+          break;
+        }
+      r = make_key(s, id);
+    }
+    o[i] = r;
+  }
+  for (int j = tid; j < b_stride; j += 256) {
+    uint64_t r = 0ull;
+    if (j < nb) {
+      const uint32_t id = key_id(lb[j]);
+      bool dup = false;
+      for (int i = 0; i < na; ++i)
+        if (key_id(la[i]) == id) {
+          dup = true;
+          break;
+        }
+      if (!dup) r = make_key(__fadd_rn(0.0f, __fdiv_rn(1.0f, __fadd_rn((float)(j + rank_base), k))), id);
+    }
+    o[a_stride + j] = r;
+  }
+}
+
+void launch_rrf(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride,
+                const int* b_cnt, int B, float k, int rank_base, int limit, uint64_t* out, int* out_cnt,
+                hipStream_t st) {
+  // `out` doubles as the fused scratch: caller provides B x (a_stride + b_stride) keys.
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_rrf, dim3(B), dim3(256), 0, st, a, a_stride, a_cnt, b, b_stride, b_cnt, k,
+                     rank_base, out);
+  HX_HIP(hipGetLastError());
+  const int stride = a_stride + b_stride;
+  launch_compact(out, stride, nullptr, B, limit < stride ? limit : stride, 0, out, stride, out_cnt,
+                 nullptr, stride, st);
+}
+
+__global__ void k_unpack(const uint64_t* keys, int64_t n, float* scores, int64_t* ids) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  scores[i] = k ? key_score(k) : -__builtin_inff();
+  ids[i] = k ? (int64_t)key_id(k) : -1;
+}
+void launch_unpack(const uint64_t* keys, int64_t n, float* scores, int64_t* ids, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, n, scores, ids);
+  HX_HIP(hipGetLastError());
+}
+
+__global__ void k_concat(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b,
+                         int b_stride, const int* b_cnt, uint64_t* out) {
+  const int q = blockIdx.x;
+  const int na = a_cnt ? (a_cnt[q] < a_stride ? a_cnt[q] : a_stride) : a_stride;
+  const int nb = b_cnt ? (b_cnt[q] < b_stride ? b_cnt[q] : b_stride) : b_stride;
+  uint64_t* o = out + (int64_t)q * (a_stride + b_stride);
+  for (int i = threadIdx.x; i < a_stride; i += blockDim.x) o[i] = i < na ? a[(int64_t)q * a_stride + i] : 0ull;
+  for (int i = threadIdx.x; i < b_stride; i += blockDim.x)
+    o[a_stride + i] = i < nb ? b[(int64_t)q * b_stride + i] : 0ull;
+}
+void launch_concat(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride,
+                   const int* b_cnt, int B, uint64_t* out, hipStream_t st) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_concat, dim3(B), dim3(256), 0, st, a, a_stride, a_cnt, b, b_stride, b_cnt, out);
+  HX_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void k_fill(T* p, int64_t n, T v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+  HX_HIP(hipGetLastError());
+}
+void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill<int>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+  HX_HIP(hipGetLastError());
+}
+
+}  // namespace hx

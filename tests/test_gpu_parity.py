@@ -1,0 +1,266 @@
+"""GPU parity: every stage of the HIP engine, called through the C ABI, against the
+numpy oracle on the same seeded inputs.  Bit-exact: ids AND fp32 score bits."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+P_MCP = dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=60, dense_limit=40,
+             quantized_limit=40, sparse_limit=50, final_limit=30, hnsw_ef=128)
+
+
+def p_fallback(n):
+    # app/services/agents/hybrid_search_workflow.py:97-106
+    return dict(matryoshka_64_limit=min(500, n // 10), matryoshka_128_limit=min(400, n // 15),
+                matryoshka_256_limit=min(300, n // 20), dense_limit=min(200, n // 25),
+                quantized_limit=min(300, n // 30), sparse_limit=min(100, n // 50), hnsw_ef=256, final_limit=10)
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rag_application_amd import engine
+    return engine
+
+
+def unpack_np(eng, keys, cnt):
+    s, i = eng.unpack(keys)
+    return s.cpu().numpy(), i.cpu().numpy(), cnt.cpu().numpy()
+
+
+def assert_list_equal(got_s, got_i, got_c, exp_s, exp_i, what=""):
+    n = len(exp_i)
+    assert got_c == n, f"{what}: count {got_c} != {n}"
+    np.testing.assert_array_equal(got_i[:n], exp_i, err_msg=f"{what}: ids")
+    np.testing.assert_array_equal(got_s[:n].view(np.uint32), np.asarray(exp_s, np.float32).view(np.uint32),
+                                  err_msg=f"{what}: score bits")
+    assert (got_i[n:] == -1).all(), f"{what}: tail ids"
+
+
+def build_pair(eng, n, dim, msizes, tables, seed=O.SEED_CORPUS, sparse=True, scale=None):
+    X = O.synth_dense(seed, 0, n, dim)
+    if scale is not None:
+        X = (X * scale[:, None]).astype(np.float32)
+    ora = O.OracleIndex(dim, msizes)
+    ix = eng.HxIndex(dim, msizes)
+    if sparse:
+        ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tables)
+        ora.add(X, ip, si, sv)
+        ix.add(X, ip, si.astype(np.int32), sv)
+    else:
+        ora.add(X)
+        ix.add(X)
+    ora.finalize()
+    return ora, ix, X
+
+
+@pytest.fixture(scope="module")
+def small(eng, synth_tables):
+    n, dim = 5000, 768
+    ora, ix, X = build_pair(eng, n, dim, (64, 128, 256), synth_tables)
+    return ora, ix, X
+
+
+def test_derived_rows_bit_exact(eng, torch_mod, synth_tables):
+    n, dim = 300, 768
+    rng = np.random.default_rng(7)
+    scale = rng.uniform(0.01, 3.0, n).astype(np.float32)
+    scale[:50] = 1.0
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    X[:25] = O.cosine_preprocess(X[:25])          # already unit rows: the keep-as-is rule
+    X[25] = 0.0                                   # zero vector
+    X[26, :] = 0.0
+    X[26, 5] = 1.0                                # one-hot
+    X = (X * scale[:, None]).astype(np.float32)
+    ora = O.OracleIndex(dim, (64, 128, 256))
+    ora.add(X)
+    ora.finalize()
+    ix = eng.HxIndex(dim, (64, 128, 256))
+    ix.add(X)
+    for r in range(n):
+        np.testing.assert_array_equal(ix.debug_row(0, r).view(np.uint32), ora.dense[r].view(np.uint32))
+        for w, m in enumerate((64, 128, 256)):
+            np.testing.assert_array_equal(ix.debug_row(w + 1, r).view(np.uint32), ora.prefix[m][r].view(np.uint32))
+        np.testing.assert_array_equal(ix.debug_row(4, r), ora.q8[r])
+    ix.close()
+
+
+@pytest.mark.parametrize("B,limit,prefix", [(1, 10, 0), (7, 10, 0), (40, 100, 0), (130, 10, 0), (33, 500, 64),
+                                            (5, 100, 64), (3, 60, 128), (3, 40, 256)])
+def test_search_dense(small, eng, torch_mod, B, limit, prefix):
+    ora, ix, _ = small
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, 768) * np.float32(1.7)   # raw queries are not unit-norm
+    keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit, prefix)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        es, ei = ora.search_dense(Q[b], limit, prefix)
+        assert_list_equal(s[b], i[b], c[b], es, ei, f"dense b={b}")
+
+
+@pytest.mark.parametrize("B,limit", [(1, 10), (9, 40), (70, 300), (129, 40)])
+def test_search_i8(small, eng, torch_mod, B, limit):
+    ora, ix, _ = small
+    Q = O.cosine_preprocess(O.synth_dense(O.SEED_QUERY, 0, B, 768))
+    keys, cnt = ix.search_i8(torch_mod.from_numpy(Q).cuda(), limit)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        es, ei = ora.search_i8(Q[b], limit)
+        assert_list_equal(s[b], i[b], c[b], es, ei, f"i8 b={b}")
+
+
+@pytest.mark.parametrize("B,limit", [(1, 10), (16, 50), (64, 100), (600, 100)])
+def test_search_sparse(small, eng, torch_mod, synth_tables, B, limit):
+    ora, ix, _ = small
+    ip, si, sv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    keys, cnt = ix.search_sparse(torch_mod.from_numpy(ip).cuda(), torch_mod.from_numpy(si.astype(np.int32)).cuda(),
+                                 torch_mod.from_numpy(sv).cuda(), limit)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(min(B, 48)):
+        es, ei = ora.search_sparse(si[ip[b]:ip[b + 1]], sv[ip[b]:ip[b + 1]], limit)
+        assert_list_equal(s[b], i[b], c[b], es, ei, f"sparse b={b}")
+
+
+def test_rescore_rrf_merge(small, eng, torch_mod):
+    ora, ix, _ = small
+    B = 6
+    rng = np.random.default_rng(3)
+    Q = O.synth_dense(O.SEED_QUERY, 100, B, 768)
+    cand = rng.integers(0, ora.n, size=(B, 90)).astype(np.int64)
+    cand[:, 10:20] = cand[:, 0:10]                      # duplicates must merge
+    cand[:, 85:] = 10 ** 7                               # ids outside the shard are skipped
+    ckeys = O.order_key(np.zeros(cand.shape, np.float32), cand).astype(np.uint64).view(np.int64)
+    ccnt = np.full(B, 90, np.int32)
+    for prefix in (0, 128):
+        keys, cnt = ix.rescore(torch_mod.from_numpy(Q).cuda(), torch_mod.from_numpy(ckeys).cuda(),
+                               torch_mod.from_numpy(ccnt).cuda(), 25, prefix)
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b in range(B):
+            es, ei = ora.rescore(Q[b], cand[b, :85], 25, prefix)
+            assert_list_equal(s[b], i[b], c[b], es, ei, f"rescore b={b}")
+    # RRF of two ranked lists
+    la = np.stack([rng.permutation(200)[:40] for _ in range(B)]).astype(np.int64)
+    lb = np.stack([rng.permutation(200)[:50] for _ in range(B)]).astype(np.int64)
+    ka = O.order_key(np.linspace(1, 0, 40, dtype=np.float32)[None, :].repeat(B, 0), la).view(np.int64)
+    kb = O.order_key(np.linspace(5, 1, 50, dtype=np.float32)[None, :].repeat(B, 0), lb).view(np.int64)
+    ca = np.array([40, 40, 17, 0, 40, 1], np.int32)
+    cb = np.array([50, 3, 50, 50, 0, 1], np.int32)
+    keys, cnt = eng.rrf(torch_mod.from_numpy(ka).cuda(), torch_mod.from_numpy(ca).cuda(),
+                        torch_mod.from_numpy(kb).cuda(), torch_mod.from_numpy(cb).cuda(), limit=10)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        es, ei = O.rrf([la[b, :ca[b]], lb[b, :cb[b]]])
+        assert_list_equal(s[b], i[b], c[b], es, ei, f"rrf b={b}")
+    # merge == top-k of the union, duplicates dropped
+    pool = np.concatenate([ka, kb], axis=1)
+    keys, cnt = eng.merge(torch_mod.from_numpy(pool).cuda(), None, 30, dedupe=True)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        u = np.unique(pool[b].view(np.uint64))[::-1][:30]
+        np.testing.assert_array_equal(keys[b].cpu().numpy().view(np.uint64)[:len(u)], u)
+
+
+@pytest.mark.parametrize("pname", ["mcp", "fallback"])
+def test_hybrid_tree(small, eng, torch_mod, synth_tables, pname):
+    ora, ix, _ = small
+    params = P_MCP if pname == "mcp" else p_fallback(ora.n)
+    B = 24
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, 768)
+    ip, si, sv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    hp = eng.make_params(params)
+    scores, ids, counts = ix.hybrid_query_host(Q, ip, si.astype(np.int32), sv, hp)
+    for b in range(B):
+        es, ei = O.hybrid_tree(ora, Q[b], si[ip[b]:ip[b + 1]], sv[ip[b]:ip[b + 1]], params)
+        assert_list_equal(scores[b], ids[b], counts[b], es, ei, f"tree[{pname}] b={b}")
+
+
+def test_hybrid_h1(small, eng, torch_mod, synth_tables):
+    ora, ix, _ = small
+    B = 24
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, 768)
+    ip, si, sv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    params = dict(P_MCP, dense_limit=100, sparse_limit=100, final_limit=10)
+    hp = eng.make_params(params, mode=eng.HX_MODE_H1)
+    scores, ids, counts = ix.hybrid_query_host(Q, ip, si.astype(np.int32), sv, hp)
+    for b in range(B):
+        es, ei = O.hybrid_h1(ora, Q[b], si[ip[b]:ip[b + 1]], sv[ip[b]:ip[b + 1]], 100, 100, 10)
+        assert_list_equal(scores[b], ids[b], counts[b], es, ei, f"h1 b={b}")
+
+
+def test_ties_and_certificate_fallback(eng, torch_mod):
+    """Duplicate rows tie exactly: the (score desc, id asc) rule decides, and a corpus
+    of near-identical rows defeats the fp16 certificate so the exact fallback runs."""
+    n, dim = 3000, 128
+    base = O.synth_dense(11, 0, 40, dim)
+    X = base[np.arange(n) % 40].copy()
+    X[1500:] += (O.synth_dense(12, 0, n - 1500, dim) * np.float32(1e-5))
+    ora = O.OracleIndex(dim, (64,))
+    ora.add(X)
+    ora.finalize()
+    ix = eng.HxIndex(dim, (64,))
+    ix.add(X)
+    Q = O.synth_dense(13, 0, 5, dim)
+    for limit, prefix in ((10, 0), (100, 0), (50, 64)):
+        keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit, prefix)
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b in range(5):
+            es, ei = ora.search_dense(Q[b], limit, prefix)
+            assert_list_equal(s[b], i[b], c[b], es, ei, f"ties b={b}")
+    assert ix.stats()["dense_fallback_queries"] > 0
+    keys, cnt = ix.search_i8(torch_mod.from_numpy(Q).cuda(), 25)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(5):
+        es, ei = ora.search_i8(Q[b], 25)
+        assert_list_equal(s[b], i[b], c[b], es, ei, f"i8 ties b={b}")
+    ix.close()
+
+
+def test_small_and_empty(eng, torch_mod, synth_tables):
+    dim = 384
+    ix = eng.HxIndex(dim, (64, 128, 256))
+    Q = O.synth_dense(O.SEED_QUERY, 0, 3, dim)
+    keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), 10)
+    assert cnt.cpu().numpy().tolist() == [0, 0, 0]
+    ora, ix2, _ = build_pair(eng, 17, dim, (64, 128, 256), synth_tables)
+    keys, cnt = ix2.search_dense(torch_mod.from_numpy(Q).cuda(), 40)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(3):
+        es, ei = ora.search_dense(Q[b], 40)
+        assert_list_equal(s[b], i[b], c[b], es, ei, "tiny")
+    assert ix2.count() == 17
+    ix.close()
+    ix2.close()
+
+
+def test_synth_fill_matches_oracle(eng, torch_mod, synth_tables):
+    n, dim = 20000, 768
+    ix = eng.HxIndex(dim, (64, 128, 256))
+    ix.synth_fill(n, O.SEED_CORPUS, O.SEED_SPDOC, synth_tables)
+    ora = O.OracleIndex(dim, (64, 128, 256))
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    ora.add(O.synth_dense(O.SEED_CORPUS, 0, n, dim), ip, si, sv)
+    ora.finalize()
+    assert ix.stats()["nnz"] == ip[-1]
+    for r in (0, 1, 777, n - 1):
+        np.testing.assert_array_equal(ix.debug_row(0, r).view(np.uint32), ora.dense[r].view(np.uint32))
+    B = 8
+    Qd = eng.synth_queries_dense(dim, 0, B, O.SEED_QUERY)
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    np.testing.assert_array_equal(Qd.cpu().numpy().view(np.uint32), Q.view(np.uint32))
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    params = dict(P_MCP, dense_limit=100, sparse_limit=100, final_limit=10)
+    hp = eng.make_params(params, mode=eng.HX_MODE_H1)
+    keys, cnt = ix.hybrid_query(Qd, torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(),
+                                torch_mod.from_numpy(qsv).cuda(), hp)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        es, ei = O.hybrid_h1(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], 100, 100, 10)
+        assert_list_equal(s[b], i[b], c[b], es, ei, f"synth h1 b={b}")
+    ix.close()
