@@ -27,6 +27,11 @@ __device__ __forceinline__ int8_t quant_i8(float x) {
   return (int8_t)(v & 0xFF);
 }
 
+// IEEE fp32 sqrt / divide through fp64 (53 >= 2*24+2 bits: the double rounding is
+// innocuous), independent of how hipcc lowers the fp32 forms.
+__device__ __forceinline__ float sqrt_f32_rn(float x) { return (float)sqrt((double)x); }
+__device__ __forceinline__ float div_f32_rn(float a, float b) { return (float)((double)a / (double)b); }
+
 __device__ __forceinline__ bool keep_unnormalised(float len2) {
   return len2 < 1.1920929e-07f || fabsf(__fsub_rn(len2, 1.0f)) <= 1.0e-6f;
 }
@@ -49,11 +54,11 @@ __global__ __launch_bounds__(256) void k_prep_rows(PrepRowsArgs a) {
   {
     const float len2 = wave_bcast_sum_sq(v, nch, lane);
     const bool keep = keep_unnormalised(len2);
-    const float ln = __fsqrt_rn(len2);
+    const float ln = sqrt_f32_rn(len2);
     float* d = a.dense + row * a.dim_pad;
     _Float16* dh = a.dense_h + row * a.dim_pad;
     for (int j = 0; j < nch; ++j) {
-      const float o = keep ? v[j] : __fdiv_rn(v[j], ln);
+      const float o = keep ? v[j] : div_f32_rn(v[j], ln);
       d[(j << 6) + lane] = o;
       dh[(j << 6) + lane] = (_Float16)o;
     }
@@ -63,10 +68,10 @@ __global__ __launch_bounds__(256) void k_prep_rows(PrepRowsArgs a) {
     const int pch = a.psize[p] >> 6;
     const float len2 = wave_bcast_sum_sq(v, pch, lane);
     const bool keep = keep_unnormalised(len2);
-    const float ln = __fsqrt_rn(len2);
+    const float ln = sqrt_f32_rn(len2);
     float* d = a.pre[p] + row * a.psize[p];
     for (int j = 0; j < pch; ++j) {
-      const float o = keep ? v[j] : __fdiv_rn(v[j], ln);
+      const float o = keep ? v[j] : div_f32_rn(v[j], ln);
       d[(j << 6) + lane] = o;
       if (p == 0 && a.pre_h0) a.pre_h0[row * a.psize[0] + (j << 6) + lane] = (_Float16)o;
     }
@@ -129,9 +134,9 @@ __global__ __launch_bounds__(256) void k_prep_queries_f(const float* q_raw, int 
   }
   const float len2 = wave_bcast_sum_sq(v, nch, lane);
   const bool keep = keep_unnormalised(len2);
-  const float ln = __fsqrt_rn(len2);
+  const float ln = sqrt_f32_rn(len2);
   for (int j = 0; j < nch; ++j) {
-    const float o = keep ? v[j] : __fdiv_rn(v[j], ln);
+    const float o = keep ? v[j] : div_f32_rn(v[j], ln);
     qn[(int64_t)b * dpad + (j << 6) + lane] = o;
     if (qh) qh[(int64_t)b * dpad + (j << 6) + lane] = (_Float16)o;
   }

@@ -218,6 +218,9 @@ void launch_certify(const uint64_t* approx_keys, int approx_stride, const int* a
 // ---------------------------------------------------------------------------------
 // reciprocal-rank fusion of two ranked lists -> unsorted fused keys (then compact)
 // ---------------------------------------------------------------------------------
+// IEEE fp32 1/x through fp64 (innocuous double rounding)
+__device__ __forceinline__ float rcp_f32_rn(float x) { return (float)(1.0 / (double)x); }
+
 __global__ __launch_bounds__(256) void k_rrf(const uint64_t* a, int a_stride, const int* a_cnt,
                                              const uint64_t* b, int b_stride, const int* b_cnt, float k,
                                              int rank_base, uint64_t* out) {
@@ -232,10 +235,10 @@ __global__ __launch_bounds__(256) void k_rrf(const uint64_t* a, int a_stride, co
     uint64_t r = 0ull;
     if (i < na) {
       const uint32_t id = key_id(la[i]);
-      float s = __fadd_rn(0.0f, __fdiv_rn(1.0f, __fadd_rn((float)(i + rank_base), k)));
+      float s = __fadd_rn(0.0f, rcp_f32_rn(__fadd_rn((float)(i + rank_base), k)));
       for (int j = 0; j < nb; ++j)
         if (key_id(lb[j]) == id) {
-          s = __fadd_rn(s, __fdiv_rn(1.0f, __fadd_rn((float)(j + rank_base), k)));
+          s = __fadd_rn(s, rcp_f32_rn(__fadd_rn((float)(j + rank_base), k)));
           break;
         }
       r = make_key(s, id);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void k_rrf(const uint64_t* a, int a_stride, co
           dup = true;
           break;
         }
-      if (!dup) r = make_key(__fadd_rn(0.0f, __fdiv_rn(1.0f, __fadd_rn((float)(j + rank_base), k))), id);
+      if (!dup) r = make_key(__fadd_rn(0.0f, rcp_f32_rn(__fadd_rn((float)(j + rank_base), k))), id);
     }
     o[a_stride + j] = r;
   }
