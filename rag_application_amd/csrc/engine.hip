@@ -8,6 +8,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -180,13 +181,21 @@ struct Geometry {
   int C;      // per-query buffer capacity (power of two <= CAND_CAP)
   int grow;   // chunk growth factor
 };
-static Geometry geometry(int L, bool approx) {
+// A chunk scanned with the threshold tau = Lp-th best of the n0 rows before it
+// appends about (grow-1)*Lp keys per query when it spans [n0, grow*n0); the pass rate
+// of that order statistic has relative standard deviation 1/sqrt(Lp).  grow is chosen
+// so that the mean plus five such deviations still fits the buffer; an overflow is
+// detected (never silent) and the query is retried with `safe` geometry.
+static Geometry geometry(int L, bool approx, bool safe) {
   Geometry g;
   g.Lp = approx ? L + std::max(32, L / 2) : L;
+  if (safe) g.Lp = std::min(std::max(2 * g.Lp, g.Lp + 256), CAND_CAP / 4);
   int c = next_pow2(std::max(8 * g.Lp, 1024));
-  g.C = std::min(c, CAND_CAP);
-  HX_CHECK(g.Lp * 2 <= g.C, "limit too large");
-  g.grow = 1 + (int)(0.7 * (g.C - g.Lp) / g.Lp);
+  g.C = safe ? CAND_CAP : std::min(c, CAND_CAP);
+  HX_CHECK(g.Lp * 2 <= g.C && g.Lp >= L, "limit too large");
+  const double per = g.Lp * (1.0 + 5.0 / std::sqrt((double)g.Lp));
+  g.grow = 1 + (int)((g.C - g.Lp) / per);
+  if (safe) g.grow = 2;
   if (g.grow < 2) g.grow = 2;
   return g;
 }
@@ -308,27 +317,49 @@ static std::vector<int> read_failures(hx_index* h, int* fail, int* nfail, int B,
 // ---------------------------------------------------------------------------------
 // stages
 // ---------------------------------------------------------------------------------
+// Re-run the failing queries of a batch as a smaller batch at `level + 1` and put
+// their rows back.  level 0 = normal geometry, level 1 = safe geometry, then exact.
+template <typename F>
+static void retry_subset(hx_index* h, const float* q_dev, const std::vector<int>& sel, int L,
+                         uint64_t* out_keys, int* out_cnt, hipStream_t st, int level, F&& run) {
+  const int ns = (int)sel.size();
+  const int off = 1000 * (level + 1);
+  float* qs = (float*)h->ws.get(WS_H_QD + off, (size_t)ns * h->dim * 4);
+  uint64_t* ks = (uint64_t*)h->ws.get(WS_H_OUT + off, (size_t)ns * L * 8);
+  int* cs = (int*)h->ws.get(WS_H_OCNT + off, (size_t)ns * 4);
+  for (int f = 0; f < ns; ++f)
+    HX_HIP(hipMemcpyAsync(qs + (int64_t)f * h->dim, q_dev + (int64_t)sel[f] * h->dim, (size_t)h->dim * 4,
+                          hipMemcpyDeviceToDevice, st));
+  run(qs, ns, ks, cs);
+  for (int f = 0; f < ns; ++f) {
+    HX_HIP(hipMemcpyAsync(out_keys + (int64_t)sel[f] * L, ks + (int64_t)f * L, (size_t)L * 8,
+                          hipMemcpyDeviceToDevice, st));
+    HX_HIP(hipMemcpyAsync(out_cnt + sel[f], cs + f, 4, hipMemcpyDeviceToDevice, st));
+  }
+}
+
 static void search_dense(hx_index* h, const float* q_dev, int B, int prefix, int L, uint64_t* out_keys,
-                         int* out_cnt, hipStream_t st) {
+                         int* out_cnt, hipStream_t st, int level = 0) {
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  const int wo = 1000 * level;  // workspace slots of this level
   const MatrixRef m = pick_matrix(h, prefix);
   const int bn = B <= 32 ? 32 : (B <= 64 ? 64 : 128);
   const int Bpad = (int)round_up(B, bn);
-  float* qn = (float*)h->ws.get(WS_QN, (size_t)B * m.dpad * 4);
-  _Float16* qh = (_Float16*)h->ws.get(WS_QH, (size_t)Bpad * m.dpad * 2);
+  float* qn = (float*)h->ws.get(WS_QN + wo, (size_t)B * m.dpad * 4);
+  _Float16* qh = (_Float16*)h->ws.get(WS_QH + wo, (size_t)Bpad * m.dpad * 2);
   launch_prep_queries_f(q_dev, h->dim, B, Bpad, m.d, m.dpad, qn, qh, st);
-  int* fail = (int*)h->ws.get(WS_FAIL, (size_t)B * 4);
-  int* nfail = (int*)h->ws.get(WS_NFAIL, 4);
+  int* fail = (int*)h->ws.get(WS_FAIL + wo, (size_t)B * 4);
+  int* nfail = (int*)h->ws.get(WS_NFAIL + wo, 4);
   std::vector<int> sel;
   if (m.m16) {
-    const Geometry g = geometry(L, true);
-    uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND, (size_t)B * g.C * 8);
-    uint64_t* cand2 = (uint64_t*)h->ws.get(WS_CAND2, (size_t)B * g.C * 8);
-    int* cnt = (int*)h->ws.get(WS_CNT, (size_t)B * 4);
-    int* ovf = (int*)h->ws.get(WS_OVF, (size_t)B * 4);
-    float* tau = (float*)h->ws.get(WS_TAU, (size_t)B * 4);
+    const Geometry g = geometry(L, true, level > 0);
+    uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND + wo, (size_t)B * g.C * 8);
+    uint64_t* cand2 = (uint64_t*)h->ws.get(WS_CAND2 + wo, (size_t)B * g.C * 8);
+    int* cnt = (int*)h->ws.get(WS_CNT + wo, (size_t)B * 4);
+    int* ovf = (int*)h->ws.get(WS_OVF + wo, (size_t)B * 4);
+    float* tau = (float*)h->ws.get(WS_TAU + wo, (size_t)B * 4);
     chunked_scan(h, KIND_F16, (const uint8_t*)m.m16, (const uint8_t*)qh, (int64_t)m.dpad * 2, B, bn, g,
                  cand, cnt, ovf, tau, nullptr, st);
     RescoreArgs r{};
@@ -350,6 +381,13 @@ static void search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
     launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st);
     sel = read_failures(h, fail, nfail, B, st);
+    if (!sel.empty() && level == 0) {
+      retry_subset(h, q_dev, sel, L, out_keys, out_cnt, st, level,
+                   [&](const float* qs, int ns, uint64_t* ks, int* cs) {
+                     search_dense(h, qs, ns, prefix, L, ks, cs, st, 1);
+                   });
+      return;
+    }
   } else {
     sel.resize((size_t)B);
     std::iota(sel.begin(), sel.end(), 0);
@@ -362,34 +400,40 @@ static void search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
 }
 
 static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* out_keys, int* out_cnt,
-                      hipStream_t st) {
+                      hipStream_t st, int level = 0) {
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  const int wo = 1000 * level;
   const int bn = B <= 32 ? 32 : (B <= 64 ? 64 : 128);
   const int Bpad = (int)round_up(B, bn);
-  int8_t* q8 = (int8_t*)h->ws.get(WS_Q8, (size_t)Bpad * h->dim_pad8);
-  float* rq = (float*)h->ws.get(WS_RINVQ, (size_t)Bpad * 4);
+  int8_t* q8 = (int8_t*)h->ws.get(WS_Q8 + wo, (size_t)Bpad * h->dim_pad8);
+  float* rq = (float*)h->ws.get(WS_RINVQ + wo, (size_t)Bpad * 4);
   launch_prep_queries_i8(q_dev, h->dim, B, Bpad, h->dim_pad8, q8, rq, st);
-  const Geometry g = geometry(L, false);
-  uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND, (size_t)B * g.C * 8);
-  int* cnt = (int*)h->ws.get(WS_CNT, (size_t)B * 4);
-  int* ovf = (int*)h->ws.get(WS_OVF, (size_t)B * 4);
-  float* tau = (float*)h->ws.get(WS_TAU, (size_t)B * 4);
-  int* fail = (int*)h->ws.get(WS_FAIL, (size_t)B * 4);
-  int* nfail = (int*)h->ws.get(WS_NFAIL, 4);
+  const Geometry g = geometry(L, false, level > 0);
+  uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND + wo, (size_t)B * g.C * 8);
+  int* cnt = (int*)h->ws.get(WS_CNT + wo, (size_t)B * 4);
+  int* ovf = (int*)h->ws.get(WS_OVF + wo, (size_t)B * 4);
+  float* tau = (float*)h->ws.get(WS_TAU + wo, (size_t)B * 4);
+  int* fail = (int*)h->ws.get(WS_FAIL + wo, (size_t)B * 4);
+  int* nfail = (int*)h->ws.get(WS_NFAIL + wo, 4);
   chunked_scan(h, KIND_I8, (const uint8_t*)h->q8, (const uint8_t*)q8, h->dim_pad8, B, bn, g, cand, cnt, ovf,
                tau, rq, st);
+  // the scan's scores are already exact: the list is final unless a buffer overflowed
   launch_compact(cand, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
   HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
   launch_certify(cand, g.C, cnt, std::numeric_limits<int>::max(), out_keys, L, out_cnt, L, ovf, 0.f, B,
                  fail, nfail, st);
   std::vector<int> sel = read_failures(h, fail, nfail, B, st);
-  if (!sel.empty()) {
-    h->i8_fallbacks += (int64_t)sel.size();
-    exact_range_fallback(h, KIND_I8, h->q8, h->dim_pad8, h->dim_pad, q8, h->dim_pad8, rq, sel, L, out_keys,
-                         out_cnt, st);
+  if (sel.empty()) return;
+  if (level == 0) {
+    retry_subset(h, q_dev, sel, L, out_keys, out_cnt, st, level,
+                 [&](const float* qs, int ns, uint64_t* ks, int* cs) { search_i8(h, qs, ns, L, ks, cs, st, 1); });
+    return;
   }
+  h->i8_fallbacks += (int64_t)sel.size();
+  exact_range_fallback(h, KIND_I8, h->q8, h->dim_pad8, h->dim_pad, q8, h->dim_pad8, rq, sel, L, out_keys,
+                       out_cnt, st);
 }
 
 static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,

@@ -169,9 +169,10 @@ __global__ __launch_bounds__(256) void k_rescore_range(RangeArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t row = a.row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.row_end) return;
-  const int b = a.qsel[blockIdx.y];
+  const int f = blockIdx.y;          // slot of this query in the fallback buffers
+  const int b = a.qsel[f];           // its index in the query batch
   const uint64_t k = exact_key(a.r, b, row, lane);
-  if (lane == 0) a.r.out[(int64_t)b * a.r.stride + a.slot0 + (row - a.row_begin)] = k;
+  if (lane == 0) a.r.out[(int64_t)f * a.r.stride + a.slot0 + (row - a.row_begin)] = k;
 }
 
 void launch_rescore_range(const RangeArgs& a, hipStream_t st) {

@@ -195,30 +195,65 @@ def test_hybrid_h1(small, eng, torch_mod, synth_tables):
 
 
 def test_ties_and_certificate_fallback(eng, torch_mod):
-    """Duplicate rows tie exactly: the (score desc, id asc) rule decides, and a corpus
-    of near-identical rows defeats the fp16 certificate so the exact fallback runs."""
+    """Duplicate rows tie exactly: the (score desc, id asc) rule decides.  A corpus of
+    near-identical rows defeats the fp16 certificate at every geometry, so the exact
+    (spec arithmetic) fallback must run and still give the oracle's list."""
     n, dim = 3000, 128
     base = O.synth_dense(11, 0, 40, dim)
-    X = base[np.arange(n) % 40].copy()
-    X[1500:] += (O.synth_dense(12, 0, n - 1500, dim) * np.float32(1e-5))
-    ora = O.OracleIndex(dim, (64,))
-    ora.add(X)
-    ora.finalize()
-    ix = eng.HxIndex(dim, (64,))
-    ix.add(X)
     Q = O.synth_dense(13, 0, 5, dim)
-    for limit, prefix in ((10, 0), (100, 0), (50, 64)):
-        keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit, prefix)
+    for mode in ("duplicates", "near-identical"):
+        if mode == "duplicates":
+            X = base[np.arange(n) % 40].copy()
+        else:
+            X = (base[0][None, :] + O.synth_dense(12, 0, n, dim) * np.float32(1e-5)).astype(np.float32)
+        ora = O.OracleIndex(dim, (64,))
+        ora.add(X)
+        ora.finalize()
+        ix = eng.HxIndex(dim, (64,))
+        ix.add(X)
+        for limit, prefix in ((10, 0), (100, 0), (50, 64)):
+            keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit, prefix)
+            s, i, c = unpack_np(eng, keys, cnt)
+            for b in range(5):
+                es, ei = ora.search_dense(Q[b], limit, prefix)
+                assert_list_equal(s[b], i[b], c[b], es, ei, f"{mode} b={b}")
+        keys, cnt = ix.search_i8(torch_mod.from_numpy(Q).cuda(), 25)
         s, i, c = unpack_np(eng, keys, cnt)
         for b in range(5):
-            es, ei = ora.search_dense(Q[b], limit, prefix)
-            assert_list_equal(s[b], i[b], c[b], es, ei, f"ties b={b}")
-    assert ix.stats()["dense_fallback_queries"] > 0
-    keys, cnt = ix.search_i8(torch_mod.from_numpy(Q).cuda(), 25)
-    s, i, c = unpack_np(eng, keys, cnt)
-    for b in range(5):
-        es, ei = ora.search_i8(Q[b], 25)
-        assert_list_equal(s[b], i[b], c[b], es, ei, f"i8 ties b={b}")
+            es, ei = ora.search_i8(Q[b], 25)
+            assert_list_equal(s[b], i[b], c[b], es, ei, f"i8 {mode} b={b}")
+        if mode == "near-identical":
+            assert ix.stats()["dense_fallback_queries"] > 0
+        ix.close()
+
+
+def test_overflow_retry_mixed_batch(eng, torch_mod):
+    """Rows sorted so that scores RISE with the row id make every chunk append almost
+    every row: candidate buffers overflow, the queries are retried with the safe
+    geometry (and, where that overflows too, exactly) and results stay exact.  Only
+    some queries of the batch are adversarial: retried rows must land in the right
+    slots of the output."""
+    n, dim = 40000, 64
+    X = O.cosine_preprocess(O.synth_dense(21, 0, n, dim))
+    Q = O.cosine_preprocess(O.synth_dense(22, 0, 6, dim))
+    order = np.argsort(O.spec_dot(X, Q[2]), kind="stable")      # ascending for query 2
+    X = X[order]
+    ora = O.OracleIndex(dim, ())
+    ora.add(X)
+    ora.finalize()
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    for limit in (10, 200):
+        keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit)
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b in range(6):
+            es, ei = ora.search_dense(Q[b], limit)
+            assert_list_equal(s[b], i[b], c[b], es, ei, f"overflow dense b={b}")
+        keys, cnt = ix.search_i8(torch_mod.from_numpy(Q).cuda(), limit)
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b in range(6):
+            es, ei = ora.search_i8(Q[b], limit)
+            assert_list_equal(s[b], i[b], c[b], es, ei, f"overflow i8 b={b}")
     ix.close()
 
 
