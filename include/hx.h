@@ -170,6 +170,19 @@ typedef struct hx_stats {
   int64_t i8_fallback_queries;
 } hx_stats;
 int hx_get_stats(hx_index* h, hx_stats* out);
+/* HIP-event profile of the hot kernels, measured on the stream they run on.
+ * Index 0 = fp16 scan (k_scan<F16>), 1 = int8 scan (k_scan<I8>), 2 = sparse scoring
+ * (k_sparse_score).  flops/bytes are ALGORITHMIC: 2*B*rows*D and rows*row_bytes +
+ * B*row_bytes per scan launch.  hx_profile_read drains what was recorded
+ * since the last read (it synchronises the recorded events). */
+typedef struct hx_prof {
+  int64_t launches[3];
+  double ms[3];
+  double flops[3];
+  double bytes[3];
+} hx_prof;
+int hx_profile(hx_index* h, int32_t enable);
+int hx_profile_read(hx_index* h, hx_prof* out);
 /* copy the derived row `row` (local) of one named vector to the host:
  * which = 0 dense f32 [dim], 1..3 prefix f32 [msizes[which-1]], 4 int8 [dim] */
 int hx_debug_row(hx_index* h, int32_t which, int64_t row, void* out_host);

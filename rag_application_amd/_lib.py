@@ -40,6 +40,11 @@ class HxStats(C.Structure):
         "dense_fallback_queries", "i8_fallback_queries")]
 
 
+class HxProf(C.Structure):
+    _fields_ = [("launches", C.c_int64 * 3), ("ms", C.c_double * 3), ("flops", C.c_double * 3),
+                ("bytes", C.c_double * 3)]
+
+
 _P = C.c_void_p
 _SIGS = {
     "hx_create": [C.c_int32, _P, C.c_int32, C.c_int32, C.c_int64, C.POINTER(_P)],
@@ -65,6 +70,8 @@ _SIGS = {
     "hx_hybrid_query_dev": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
     "hx_get_stats": [_P, C.POINTER(HxStats)],
     "hx_debug_row": [_P, C.c_int32, C.c_int64, _P],
+    "hx_profile": [_P, C.c_int32],
+    "hx_profile_read": [_P, C.POINTER(HxProf)],
 }
 EXPORTS = tuple(_SIGS) + ("hx_last_error",)
 

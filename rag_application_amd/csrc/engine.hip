@@ -86,6 +86,11 @@ struct hx_index {
   int64_t sp_docs_built = 0;
   Workspace ws;
   int64_t dense_fallbacks = 0, i8_fallbacks = 0;
+  // optional HIP-event profile of the scan / sparse kernels (hx_profile)
+  struct ProfRec { hipEvent_t a, b; int what; double flops, bytes; };
+  bool prof = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
 
   void set_device() const { HX_HIP(hipSetDevice(device)); }
 };
@@ -218,6 +223,34 @@ static void zero_outputs(uint64_t* keys, int* cnt, int B, int L, hipStream_t st)
   HX_HIP(hipMemsetAsync(cnt, 0, (size_t)B * 4, st));
 }
 
+struct ProfScope {
+  hx_index* h;
+  hipStream_t st;
+  hx_index::ProfRec rec{};
+  bool on;
+  ProfScope(hx_index* h_, hipStream_t st_, int what, double flops, double bytes) : h(h_), st(st_), on(h_->prof) {
+    if (!on) return;
+    if (h->prof_pool.empty()) {
+      hipEvent_t a, b;
+      HX_HIP(hipEventCreate(&a));
+      HX_HIP(hipEventCreate(&b));
+      h->prof_pool.emplace_back(a, b);
+    }
+    rec.a = h->prof_pool.back().first;
+    rec.b = h->prof_pool.back().second;
+    h->prof_pool.pop_back();
+    rec.what = what;
+    rec.flops = flops;
+    rec.bytes = bytes;
+    HX_HIP(hipEventRecord(rec.a, st));
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.b, st);
+    h->prof_recs.push_back(rec);
+  }
+};
+
 // scan all rows with geometric chunks; leaves the best `keep` keys (sorted) in cand
 static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t* Q, int64_t row_bytes, int B,
                          int bn, const Geometry& g, uint64_t* cand, int* cnt, int* ovf, float* tau,
@@ -243,7 +276,12 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   while (r0 < h->n) {
     a.row_begin = r0;
     a.row_end = r1;
-    launch_scan(a, kind, bn, st);
+    {
+      const double rows = (double)(r1 - r0);
+      const double elems = kind == KIND_F16 ? (double)row_bytes / 2.0 : (double)row_bytes;
+      ProfScope ps(h, st, kind, 2.0 * B * rows * elems, rows * (double)row_bytes + (double)B * row_bytes);
+      launch_scan(a, kind, bn, st);
+    }
     launch_compact(cand, g.C, cnt, B, g.Lp, 0, cand, g.C, cnt, tau, g.C, st);
     r0 = r1;
     // rows per launch bounded so the kernel's 32-bit tile counters cannot wrap
@@ -464,7 +502,10 @@ static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q
   a.limit = L;
   a.out = pk;
   a.out_cnt = pc;
-  launch_sparse_score(a, st);
+  {
+    ProfScope ps(h, st, 2, 0.0, 0.0);
+    launch_sparse_score(a, st);
+  }
   launch_compact(pk, parts * L, nullptr, B, L, 0, out_keys, L, out_cnt, nullptr, parts * L, st);
 }
 
@@ -966,6 +1007,33 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   out->bytes_sparse = h->nnz * 6 + (int64_t)h->sp.table_cap * (int64_t)sizeof(SpHashEntry);
   out->dense_fallback_queries = h->dense_fallbacks;
   out->i8_fallback_queries = h->i8_fallbacks;
+  HX_CATCH
+}
+
+int hx_profile(hx_index* h, int32_t enable) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  h->prof = enable != 0;
+  HX_CATCH
+}
+
+int hx_profile_read(hx_index* h, hx_prof* out) {
+  HX_TRY
+  HX_CHECK(h && out, "NULL argument");
+  h->set_device();
+  std::memset(out, 0, sizeof(*out));
+  for (auto& r : h->prof_recs) {
+    HX_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HX_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    const int w = r.what;  // 0 f16 scan, 1 i8 scan, 2 sparse
+    out->launches[w] += 1;
+    out->ms[w] += ms;
+    out->flops[w] += r.flops;
+    out->bytes[w] += r.bytes;
+    h->prof_pool.emplace_back(r.a, r.b);
+  }
+  h->prof_recs.clear();
   HX_CATCH
 }
 

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import HX_MODE_H1, HX_MODE_TREE, HxError, HxParams, HxStats, check
+from ._lib import HX_MODE_H1, HX_MODE_TREE, HxError, HxParams, HxProf, HxStats, check
 
 SEARCH_PARAM_KEYS = ("matryoshka_64_limit", "matryoshka_128_limit", "matryoshka_256_limit",
                      "dense_limit", "quantized_limit", "sparse_limit", "final_limit", "hnsw_ef")
@@ -119,6 +119,16 @@ class HxIndex:
         s = HxStats()
         check(_lib.lib().hx_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in HxStats._fields_}
+
+    def profile(self, enable: bool):
+        check(_lib.lib().hx_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self) -> dict:
+        p = HxProf()
+        check(_lib.lib().hx_profile_read(self._h, C.byref(p)))
+        names = ("scan_f16", "scan_i8", "sparse")
+        return {n: dict(launches=p.launches[i], ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i])
+                for i, n in enumerate(names)}
 
     def debug_row(self, which: int, row: int) -> np.ndarray:
         if which == 4:
