@@ -1,0 +1,99 @@
+"""Row-sharded search across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+Every ranking stage of the reference query (qdrant_handler.py:305-372) is "top-L of a
+score over all documents", and top-L(union of shards) is a subset of the union of the
+shards' top-L lists.  So each stage runs on the local shard, the per-shard lists (64-bit
+keys: score + GLOBAL row id) are all-gathered, and every rank merges them into the same
+global list.  Nested stages then re-score only their OWN rows among the global survivors
+and exchange again; RRF runs after the gather because its ranks are global.  Payloads
+are tiny (B x L x 8 bytes per rank), i.e. latency-bound: one all-gather per stage, no
+ring of its own.  The reference has no multi-device path at all."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class ShardedIndex:
+    """`local` is this rank's shard: anything with the stage methods of
+    `engine.HxIndex` (search_dense / search_i8 / search_sparse / rescore).  `ops`
+    provides merge(keys, counts, limit, dedupe) and rrf(a, ac, b, bc, limit, k,
+    rank_base): the HIP implementations of `engine` by default (tests inject a CPU
+    checker to exercise the exchange logic over gloo)."""
+
+    def __init__(self, local, group: Optional[dist.ProcessGroup] = None, ops=None):
+        self.local = local
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if ops is None:
+            from . import engine as ops  # HIP kernels
+        self.ops = ops
+
+    # -- exchange ---------------------------------------------------------------------
+    def gather(self, keys: torch.Tensor) -> torch.Tensor:
+        """[B, L] per rank -> [B, world*L] (rank-major inside a row), same on every rank."""
+        if self.world == 1:
+            return keys
+        B, L = keys.shape
+        out = torch.empty((self.world * B, L), dtype=keys.dtype, device=keys.device)   # rank-major concat
+        dist.all_gather_into_tensor(out, keys.contiguous(), group=self.group)
+        return out.view(self.world, B, L).permute(1, 0, 2).reshape(B, -1)
+
+    def _global(self, keys, limit, dedupe=False):
+        if self.world == 1:
+            return keys, None
+        return self.ops.merge(self.gather(keys), None, limit, dedupe)
+
+    # -- stages: global lists, replicated on every rank ----------------------------------
+    def search_dense(self, q, limit, prefix=0):
+        k, c = self.local.search_dense(q, limit, prefix)
+        return (k, c) if self.world == 1 else self._global(k, limit)
+
+    def search_i8(self, q, limit):
+        k, c = self.local.search_i8(q, limit)
+        return (k, c) if self.world == 1 else self._global(k, limit)
+
+    def search_sparse(self, q_indptr, q_idx, q_val, limit):
+        k, c = self.local.search_sparse(q_indptr, q_idx, q_val, limit)
+        return (k, c) if self.world == 1 else self._global(k, limit)
+
+    def rescore(self, q, cand_keys, cand_counts, limit, prefix=0):
+        # each rank scores the candidates that live in its shard (others are skipped)
+        k, c = self.local.rescore(q, cand_keys, cand_counts, limit, prefix)
+        return (k, c) if self.world == 1 else self._global(k, limit)
+
+    # -- whole queries -----------------------------------------------------------------------
+    def hybrid_h1(self, q, q_indptr, q_idx, q_val, dense_limit=100, sparse_limit=100, limit=10,
+                  rrf_k=2.0, rank_base=0):
+        dk, dc = self.local.search_dense(q, dense_limit)
+        sk, sc = self.local.search_sparse(q_indptr, q_idx, q_val, sparse_limit)
+        if self.world > 1:  # one exchange carries both lists
+            allk = self.gather(torch.cat([dk, sk], dim=1)).reshape(q.shape[0], self.world, -1)
+            dk, dc = self.ops.merge(allk[:, :, :dense_limit].reshape(q.shape[0], -1), None, dense_limit, False)
+            sk, sc = self.ops.merge(allk[:, :, dense_limit:].reshape(q.shape[0], -1), None, sparse_limit, False)
+        return self.ops.rrf(dk, dc, sk, sc, limit, rrf_k, rank_base)
+
+    def hybrid_tree(self, q, q_indptr, q_idx, q_val, p: dict, msizes=(64, 128, 256), rrf_k=2.0, rank_base=0,
+                    rrf_limit=10):
+        """The reference tree with one exchange per cascade level."""
+        lim = [p[f"matryoshka_{m}_limit"] for m in msizes]
+        if msizes:
+            ck, cc = self.search_dense(q, lim[0], msizes[0])
+            for m, l in zip(msizes[1:], lim[1:]):
+                ck, cc = self.rescore(q, ck, cc, l, m)
+            ak, ac = self.rescore(q, ck, cc, p["dense_limit"], 0)
+        else:
+            ak, ac = self.search_dense(q, p["dense_limit"], 0)
+        qk, qc = self.search_i8(q, p["quantized_limit"])
+        dk, dc = self.rescore(q, qk, qc, p["dense_limit"], 0)
+        sk, sc = self.search_sparse(q_indptr, q_idx, q_val, p["sparse_limit"])
+        if dc is None:
+            dc = torch.full((q.shape[0],), dk.shape[1], dtype=torch.int32, device=dk.device)
+        if sc is None:
+            sc = torch.full((q.shape[0],), sk.shape[1], dtype=torch.int32, device=sk.device)
+        rk, rc = self.ops.rrf(dk, dc, sk, sc, rrf_limit, rrf_k, rank_base)
+        uk = torch.cat([ak, rk], dim=1)     # empty slots are 0 and are ignored downstream
+        return self.rescore(q, uk, None, p["final_limit"], 0)

@@ -1,0 +1,299 @@
+"""Drop-in for the reference's `QdrantHandler`
+(app/core/vector_store/qdrant/qdrant_handler.py:14-481): same class name, same async
+methods, same argument meaning and the same error conventions -- search and count
+never raise (they return [] / 0, :384-386, :479-481), mutations re-raise (:196-198,
+:265-267, :437-439), `create_collection` raises ValueError on an empty user id
+(:39-40).  Where the reference ships a Prefetch tree to a Qdrant server over HTTP
+(:363-372), this class calls the HIP engine through the C ABI (include/hx.h).
+
+Additive: `hybrid_search_batch` (the reference is strictly one query per call) and a
+configurable dense size (the reference hard-codes 768, :138-139; that stays the
+default)."""
+from __future__ import annotations
+
+import asyncio
+import logging
+import threading
+import uuid
+from dataclasses import asdict, dataclass, field
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from . import engine as _engine
+from ._lib import HX_MODE_TREE
+
+
+@dataclass
+class ScoredPoint:
+    """What callers duck-type on (qdrant_handler.py:377;
+    app/services/agents/search_orchestration_workflow.py:70-73, 168-175)."""
+    id: str
+    version: int
+    score: float
+    payload: Optional[Dict[str, Any]] = None
+    vector: Optional[Any] = None
+    shard_key: Optional[Any] = None
+    order_value: Optional[Any] = None
+
+    def dict(self):
+        return asdict(self)
+
+    model_dump = dict
+
+
+@dataclass
+class SparseVector:
+    """Shape-compatible with qdrant_client.http.models.SparseVector."""
+    indices: List[int] = field(default_factory=list)
+    values: List[float] = field(default_factory=list)
+
+
+def _sparse_parts(sv):
+    """Accept {"indices": [...], "values": [...]} or an object with .indices/.values
+    (qdrant_handler.py:348-351)."""
+    if isinstance(sv, dict):
+        return sv["indices"], sv["values"]
+    return sv.indices, sv.values
+
+
+class _Collection:
+    def __init__(self, dim, msizes, device):
+        self.dim = dim
+        self.msizes = tuple(msizes)
+        self.index = _engine.HxIndex(dim, self.msizes, device=device)
+        self.ids: List[str] = []
+        self.payloads: List[Dict[str, Any]] = []
+        self.sparse_enabled = True
+
+    def close(self):
+        self.index.close()
+
+
+class QdrantHandler:
+    """Handles vector operations for hybrid search with dense and sparse vectors."""
+
+    def __init__(self, reranker=None, device: int = 0):
+        # The reference loads jinaai/jina-colbert-v2 here (:17-22) and falls back to the
+        # un-reranked list whenever reranking raises (:410-412).  `reranker` is any object
+        # with rerank_documents(query, documents, max_tokens) -> list of indices.
+        self.reranker = reranker
+        self.device = device
+        self._collections: Dict[str, _Collection] = {}
+        self._lock = threading.Lock()
+
+    async def _run(self, fn, *a):
+        loop = asyncio.get_running_loop()
+
+        def locked():
+            with self._lock:
+                return fn(*a)
+        return await loop.run_in_executor(None, locked)
+
+    # ---------------------------------------------------------------- create_collection
+    async def create_collection(self, user_id: str, dense_vector_size: int = 768,
+                                matryoshka_sizes: list = [64, 128, 256], quantized_size: int = 768,
+                                sparse_enabled: bool = True, force_recreate: bool = False):
+        try:
+            if not user_id:
+                raise ValueError("user_id cannot be empty")
+            user_id = str(user_id)
+            if user_id in self._collections and not force_recreate:
+                logging.info(f"Collection for user {user_id} already exists, skipping creation")
+                return
+            if quantized_size != dense_vector_size:
+                raise ValueError("quantized_size must equal dense_vector_size")
+
+            def make():
+                old = self._collections.pop(user_id, None)
+                if old is not None:
+                    old.close()
+                col = _Collection(int(dense_vector_size), [int(m) for m in matryoshka_sizes], self.device)
+                col.sparse_enabled = bool(sparse_enabled)
+                self._collections[user_id] = col
+            await self._run(make)
+            logging.info(f"Created hybrid search collection for user {user_id}")
+        except ValueError as ve:
+            logging.error(f"Validation error creating collection for user {user_id}: {str(ve)}")
+            raise
+        except Exception as e:
+            logging.critical(f"Collection creation failed for user {user_id}: {str(e)}")
+            raise
+
+    # --------------------------------------------------------------------------- upserts
+    async def _store(self, user_id, items, emb_key_payload):
+        if str(user_id) not in self._collections:
+            await self.create_collection(user_id=user_id)
+        col = self._collections[str(user_id)]
+        dense, indptr, idx, val, ids, payloads = [], [0], [], [], [], []
+        for item in items:
+            if len(item["dense_embedding"]) != col.dim:
+                raise ValueError(
+                    f"Dense vector dimension mismatch. Expected {col.dim}, got {len(item['dense_embedding'])}")
+            dense.append(np.asarray(item["dense_embedding"], dtype=np.float32))
+            si, sv = _sparse_parts(item["sparse_embedding"]) if col.sparse_enabled else ([], [])
+            idx.extend(int(i) for i in si)
+            val.extend(float(v) for v in sv)
+            indptr.append(len(idx))
+            ids.append(str(uuid.uuid4()))
+            payloads.append(emb_key_payload(item))
+        if not dense:
+            return 0
+
+        def add():
+            col.index.add(np.stack(dense), np.asarray(indptr, np.int64), np.asarray(idx, np.int32),
+                          np.asarray(val, np.float32))
+            col.ids.extend(ids)
+            col.payloads.extend(payloads)
+        await self._run(add)
+        return len(dense)
+
+    async def store_document_vectors(self, embedded_chunks: List[Dict[str, Any]], user_id: str):
+        """Stores document chunks with multi-stage embeddings (qdrant_handler.py:120-198)."""
+        try:
+            def payload(chunk):
+                metadata = chunk["chunk_metadata"]
+                return {
+                    "document_id": metadata["document_id"],
+                    "user_id": metadata["user_id"],
+                    "file_name": metadata["file_name"],
+                    "mime_type": metadata["mime_type"],
+                    "file_size": metadata["file_size"],
+                    "file_description": metadata["description"],
+                    "file_path": metadata["file_path"],
+                    "context_version": metadata["context_version"],
+                    "chunk_number": metadata["chunk_number"],
+                    "entities": metadata.get("entities"),
+                    "relationships": metadata.get("relationships"),
+                    "context": metadata.get("context"),
+                    "document_summary": metadata["doc_summary"],
+                    "content": str(chunk["content"]),
+                    "page_number": metadata.get("page_number"),
+                    "languages": metadata.get("languages"),
+                    "element_id": metadata.get("element_id"),
+                    "is_continuation": metadata.get("is_continuation"),
+                    "category": metadata.get("category"),
+                }
+            n = await self._store(user_id, embedded_chunks, payload)
+            logging.info(f"Stored {n} chunks with multi-stage embeddings for user {user_id}")
+        except Exception as e:
+            logging.error(f"Failed to store vectors: {str(e)}")
+            raise
+
+    async def store_chat_vectors(self, embedded_payload: List[Dict[str, Any]], user_id: str):
+        """Stores chat message vectors (qdrant_handler.py:200-267)."""
+        try:
+            def payload(chat):
+                ts = chat["timestamp"]
+                return {
+                    "chat_id": chat["chat_id"],
+                    "user_id": user_id,
+                    "message_type": chat["message_type"],
+                    "timestamp": ts.isoformat() if hasattr(ts, "isoformat") else ts,
+                    "entities": chat["entities"],
+                    "relationships": chat["relationships"],
+                    "chat_summary": chat["chat_summary"],
+                    "content": chat["message"],
+                    "is_chat": True,
+                }
+            n = await self._store(user_id, embedded_payload, payload)
+            logging.info(f"Stored {n} chat messages with embeddings for user {user_id}")
+        except Exception as e:
+            logging.error(f"Failed to store chat vectors: {str(e)}")
+            raise
+
+    # ---------------------------------------------------------------------------- search
+    def _search_sync(self, user_id, dense_vectors, sparse_vectors, search_params, filters):
+        if filters:
+            raise NotImplementedError("payload filters are not supported yet (no reference call site uses them)")
+        col = self._collections[str(user_id)]
+        q = np.asarray(dense_vectors, dtype=np.float32).reshape(len(sparse_vectors), -1)
+        if q.shape[1] != col.dim:
+            raise ValueError(f"query dimension {q.shape[1]} != collection dimension {col.dim}")
+        indptr, idx, val = [0], [], []
+        for sv in sparse_vectors:
+            si, vv = _sparse_parts(sv)
+            idx.extend(int(i) for i in si)
+            val.extend(float(v) for v in vv)
+            indptr.append(len(idx))
+        hp = _engine.make_params(search_params, mode=HX_MODE_TREE)   # KeyError/TypeError like the reference
+        scores, ids, counts = col.index.hybrid_query_host(
+            q, np.asarray(indptr, np.int64), np.asarray(idx, np.int32), np.asarray(val, np.float32), hp)
+        out = []
+        for b in range(q.shape[0]):
+            out.append([ScoredPoint(id=col.ids[int(r)], version=0, score=float(s), payload=col.payloads[int(r)])
+                        for s, r in zip(scores[b, :counts[b]], ids[b, :counts[b]])])
+        return out
+
+    async def hybrid_search(self, user_id: str, query_text: str, dense_vector: List[float],
+                            sparse_vector: Dict[str, List[float]], image_embedding: Optional[List[float]] = None,
+                            top_k: int = 10, search_params: Optional[Dict[str, Any]] = None,
+                            filters: Optional[Dict] = None) -> List[Dict]:
+        """Matryoshka cascade, quantized + dense refinement, sparse, RRF, dense root
+        re-score, reranking hook (qdrant_handler.py:269-386)."""
+        try:
+            results = (await self._run(self._search_sync, user_id, [dense_vector], [sparse_vector],
+                                       search_params, filters))[0]
+            max_tokens_per_doc = 8000 // top_k
+            documents = [res.payload["content"] for res in results
+                         if hasattr(res, "payload") and res.payload and "content" in res.payload]
+            reranked_results = await self.rerank_with_colbert(query_text, documents, results, max_tokens_per_doc)
+            return reranked_results[:top_k]
+        except Exception as e:
+            logging.error(f"Hybrid search failed for user {user_id}: {str(e)}")
+            return []
+
+    async def hybrid_search_batch(self, user_id: str, dense_vectors, sparse_vectors, top_k: int = 10,
+                                  search_params: Optional[Dict[str, Any]] = None,
+                                  filters: Optional[Dict] = None) -> List[List[ScoredPoint]]:
+        """B queries in one engine call (additive; no reranking hook)."""
+        try:
+            res = await self._run(self._search_sync, user_id, dense_vectors, sparse_vectors, search_params, filters)
+            return [r[:top_k] for r in res]
+        except Exception as e:
+            logging.error(f"Hybrid search failed for user {user_id}: {str(e)}")
+            return []
+
+    async def rerank_with_colbert(self, query: str, documents: List[str], results: List[Dict],
+                                  max_tokens: int) -> List[Dict]:
+        """qdrant_handler.py:388-412: reorder by reranker indices; any failure keeps the order."""
+        try:
+            client = getattr(self.reranker, "client", self.reranker)
+            ranked_indices = client.rerank_documents(query, documents, max_tokens)
+            if not ranked_indices:
+                return results
+            return [results[i] for i in ranked_indices]
+        except Exception as e:
+            logging.error(f"Reranking failed: {str(e)}")
+            return results
+
+    # ------------------------------------------------------------------------ collections
+    async def get_all_containers(self) -> List[str]:
+        try:
+            return list(self._collections.keys())
+        except Exception as e:
+            logging.error(f"Failed to fetch user collections: {str(e)}")
+            return []
+
+    async def delete_collection(self, user_id: str):
+        try:
+            def drop():
+                col = self._collections.pop(str(user_id))   # KeyError if absent: re-raised
+                col.close()
+            await self._run(drop)
+            logging.info(f"Deleted collection for user {user_id}")
+        except Exception as e:
+            logging.error(f"Failed to delete collection for user {user_id}: {str(e)}")
+            raise
+
+    async def get_collection_chunk_count(self, user_id: str, filters: Optional[Dict] = None) -> int:
+        try:
+            if str(user_id) not in self._collections:
+                logging.warning(f"Collection for user {user_id} does not exist.")
+                return 0
+            if filters:
+                raise NotImplementedError("payload filters are not supported yet")
+            return await self._run(self._collections[str(user_id)].index.count)
+        except Exception as e:
+            logging.error(f"Failed to get chunk count for user {user_id}: {str(e)}")
+            return 0

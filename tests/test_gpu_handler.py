@@ -1,0 +1,65 @@
+"""GPU: the QdrantHandler drop-in end to end (what test/test_hybrid_search.py of the
+reference exercises, without the HTTP layer): ingest ~1k text chunks, query, and get
+a list whose elements expose .payload["content"] / ["file_name"]."""
+import asyncio
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run(c):
+    return asyncio.run(c)
+
+
+def test_handler_plumbing_and_parity():
+    from rag_application_amd import bm25
+    from rag_application_amd.handler import QdrantHandler
+    h = QdrantHandler()
+    words = ("vector search engine retrieval hybrid dense sparse index document chunk query ranking fusion "
+             "matrix memory bandwidth kernel wavefront shard payload embedding quantized cosine").split()
+    rng = np.random.default_rng(5)
+    n, dim = 1000, 768
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    chunks, ora_sp = [], []
+    for r in range(n):
+        text = " ".join(rng.choice(words, size=int(rng.integers(5, 40))))
+        idx, val = bm25.embed(text)
+        ora_sp.append((idx, val))
+        chunks.append({"content": text, "dense_embedding": X[r].tolist(),
+                       "sparse_embedding": {"indices": idx, "values": val},
+                       "chunk_metadata": {"document_id": "d", "user_id": "u", "file_name": f"f{r % 7}.txt",
+                                          "mime_type": "text/plain", "file_size": 1, "description": "", "file_path": "/x",
+                                          "context_version": 1, "chunk_number": r, "doc_summary": "s"}})
+    with pytest.raises(ValueError):
+        run(h.store_document_vectors([dict(chunks[0], dense_embedding=[0.0] * 384)], "u"))   # :138-139
+    run(h.store_document_vectors(chunks[:600], "u"))
+    run(h.store_document_vectors(chunks[600:], "u"))
+    assert run(h.get_collection_chunk_count("u")) == n
+    assert run(h.get_all_containers()) == ["u"]
+    params = dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=60, dense_limit=40,
+                  quantized_limit=40, sparse_limit=50, final_limit=30, hnsw_ef=128)
+    qtext = "hybrid dense sparse retrieval"
+    qi, qv = bm25.embed(qtext)
+    q = O.synth_dense(O.SEED_QUERY, 0, 1, dim)[0]
+    res = run(h.hybrid_search("u", qtext, q.tolist(), {"indices": qi, "values": qv}, top_k=5, search_params=params))
+    assert isinstance(res, list) and len(res) == 5
+    assert all(hasattr(r, "payload") and "content" in r.payload and "file_name" in r.payload for r in res)
+    # parity with the oracle tree on the same inputs
+    ora = O.OracleIndex(dim, (64, 128, 256))
+    ip = np.cumsum([0] + [len(i) for i, _ in ora_sp])
+    ora.add(X, ip, np.concatenate([np.asarray(i, np.int64) for i, _ in ora_sp]),
+            np.concatenate([np.asarray(v, np.float32) for _, v in ora_sp]))
+    es, ei = O.hybrid_tree(ora, q, np.asarray(qi), np.asarray(qv, np.float32), params)
+    assert [r.payload["chunk_number"] for r in res] == ei[:5].tolist()
+    np.testing.assert_array_equal(np.array([r.score for r in res], np.float32).view(np.uint32), es[:5].view(np.uint32))
+    # reference conventions
+    assert run(h.hybrid_search("u", qtext, q.tolist(), {"indices": qi, "values": qv}, search_params=None)) == []
+    batch = run(h.hybrid_search_batch("u", [q.tolist()] * 3, [{"indices": qi, "values": qv}] * 3, top_k=4,
+                                      search_params=params))
+    assert [len(b) for b in batch] == [4, 4, 4] and batch[0][0].id == res[0].id
+    run(h.delete_collection("u"))
+    assert run(h.get_collection_chunk_count("u")) == 0

@@ -299,3 +299,80 @@ def test_synth_fill_matches_oracle(eng, torch_mod, synth_tables):
         es, ei = O.hybrid_h1(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], 100, 100, 10)
         assert_list_equal(s[b], i[b], c[b], es, ei, f"synth h1 b={b}")
     ix.close()
+
+
+def test_two_shards_one_gpu_merge_equals_unsharded(eng, torch_mod, synth_tables):
+    """Row sharding through the HIP path: two shards (id_base 0 and n/2) on one GPU,
+    per-stage lists concatenated the way the RCCL all-gather lays them out, merged by
+    hx_merge, nested stages re-scored per shard.  Must equal the unsharded oracle."""
+    n, dim, B = 6000, 256, 9
+    tabs = synth_tables
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
+    ora = O.OracleIndex(dim, (64, 128))
+    ora.add(X, ip, si, sv)
+    ora.finalize()
+    h = n // 2
+    shards = []
+    for r0, r1 in ((0, h), (h, n)):
+        ix = eng.HxIndex(dim, (64, 128), id_base=r0)
+        ix.add(X[r0:r1], ip[r0:r1 + 1] - ip[r0], si[ip[r0]:ip[r1]].astype(np.int32), sv[ip[r0]:ip[r1]])
+        shards.append(ix)
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, tabs)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(),
+          torch_mod.from_numpy(qsv).cuda())
+
+    def glob(parts, limit, dedupe=False):
+        return eng.merge(torch_mod.cat([k for k, _ in parts], dim=1), None, limit, dedupe)
+
+    # cascade: m64 scan -> m128 -> dense, one "exchange" per level
+    c = glob([s.search_dense(Qd, 80, 64) for s in shards], 80)
+    c = glob([s.rescore(Qd, c[0], c[1], 50, 128) for s in shards], 50)
+    a = glob([s.rescore(Qd, c[0], c[1], 30, 0) for s in shards], 30)
+    q8 = glob([s.search_i8(Qd, 35) for s in shards], 35)
+    dq = glob([s.rescore(Qd, q8[0], q8[1], 30, 0) for s in shards], 30)
+    sp = glob([s.search_sparse(*tq, 25) for s in shards], 25)
+    r = eng.rrf(dq[0], dq[1], sp[0], sp[1], limit=10)
+    u = torch_mod.cat([a[0], r[0]], dim=1)
+    out = glob([s.rescore(Qd, u, None, 12, 0) for s in shards], 12)
+    s_, i_, c_ = unpack_np(eng, *out)
+    P = dict(matryoshka_64_limit=80, matryoshka_128_limit=50, dense_limit=30, quantized_limit=35, sparse_limit=25,
+             final_limit=12, hnsw_ef=1)
+    for b in range(B):
+        es, ei = O.hybrid_tree(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], P)
+        assert_list_equal(s_[b], i_[b], c_[b], es, ei, f"sharded tree b={b}")
+    for s in shards:
+        s.close()
+
+
+def test_golden_fixtures_through_the_abi(eng, torch_mod, synth_tables):
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corpus_a_2048x768.npz"))
+    n, dim, B = 2048, 768, 32
+    ix = eng.HxIndex(dim, (64, 128, 256))
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    ix.add(O.synth_dense(O.SEED_CORPUS, 0, n, dim), ip, si.astype(np.int32), sv)
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(),
+          torch_mod.from_numpy(qsv).cuda())
+
+    def chk(name, keys, cnt):
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b in range(B):
+            m = gold[name + "_cnt"][b]
+            assert c[b] == m
+            np.testing.assert_array_equal(i[b, :m], gold[name + "_ids"][b, :m])
+            np.testing.assert_array_equal(s[b, :m].view(np.uint32), gold[name + "_bits"][b, :m])
+    chk("dense", *ix.search_dense(Qd, 10))
+    chk("m64", *ix.search_dense(Qd, 10, 64))
+    chk("i8", *ix.search_i8(Qd, 10))
+    chk("sparse", *ix.search_sparse(*tq, 10))
+    chk("tree_mcp", *ix.hybrid_query(Qd, *tq, eng.make_params(P_MCP)))
+    chk("tree_fallback", *ix.hybrid_query(Qd, *tq, eng.make_params(p_fallback(n))))
+    chk("h1", *ix.hybrid_query(Qd, *tq, eng.make_params(dict(P_MCP, dense_limit=100, sparse_limit=100, final_limit=10),
+                                                        mode=eng.HX_MODE_H1)))
+    ix.close()
