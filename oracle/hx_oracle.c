@@ -328,12 +328,12 @@ static int64_t find_term(const ho_inv* iv, int32_t term) {
   return (lo < iv->n_terms && iv->terms[lo] == term) ? lo : -1;
 }
 
-/* query terms ascending (the summation order); score = sum q_t*d_t (fp32 mul, fp32 add) */
+/* score = f32(sum_t rint(f64(q_t)*f64(d_t)*2^40)) * 2^-40 : order-independent (oracle.py) */
 void ho_search_sparse(const ho_inv* iv, const int64_t* qip, const int32_t* qix, const float* qv, int B,
                       int L, int64_t id_base, float* out_s, int64_t* out_i, int* out_c) {
 #pragma omp parallel
   {
-    float* acc = (float*)calloc((size_t)(iv->n_docs + 1), 4);
+    int64_t* acc = (int64_t*)calloc((size_t)(iv->n_docs + 1), 8);
     uint8_t* seen = (uint8_t*)calloc((size_t)(iv->n_docs + 1), 1);
     int32_t* touched = (int32_t*)malloc((size_t)(iv->n_docs + 1) * 4);
     uint64_t* hk = (uint64_t*)malloc((size_t)(L > 0 ? L : 1) * 8);
@@ -346,7 +346,7 @@ void ho_search_sparse(const ho_inv* iv, const int64_t* qip, const int32_t* qix, 
         const float qw = qv[j];
         for (int64_t i = iv->off[t]; i < iv->off[t + 1]; ++i) {
           const int32_t d = iv->doc[i];
-          acc[d] = acc[d] + qw * iv->w[i];
+          acc[d] += (int64_t)nearbyint(((double)qw * (double)iv->w[i]) * 1099511627776.0);
           if (!seen[d]) {
             seen[d] = 1;
             touched[nt++] = d;
@@ -356,8 +356,8 @@ void ho_search_sparse(const ho_inv* iv, const int64_t* qip, const int32_t* qix, 
       heap_t h = {hk, 0, L};
       for (int64_t i = 0; i < nt; ++i) {
         const int32_t d = touched[i];
-        heap_push(&h, make_key(acc[d], (uint32_t)(id_base + d)));
-        acc[d] = 0.0f;
+        heap_push(&h, make_key((float)acc[d] * 9.094947017729282e-13f, (uint32_t)(id_base + d)));
+        acc[d] = 0;
         seen[d] = 0;
       }
       emit_sorted(hk, h.n, L, out_s + (int64_t)b * L, out_i + (int64_t)b * L, out_c + b);

@@ -21,6 +21,9 @@ upstream behaviour, unverifiable offline".
 Arithmetic contract (shared bit-for-bit with oracle/hx_oracle.c and the HIP
 engine; all fp32 operations are IEEE round-to-nearest, UNFUSED mul then add):
 
+sparse score        : sum over matching terms of rint(f64(q_t)*f64(d_t)*2^40) as int64,
+                      then f32(sum) * 2^-40 (order-independent restatement of upstream's
+                      fp32 running sum; differs from it by a few fp32 ulps at most).
 ``spec_dot(x, q)``  : zero-pad to a multiple of 64; lane l (0..63) accumulates
                       p_l = p_l + x[64j+l]*q[64j+l] for j ascending from +0;
                       then p_l += p_{l+off} for off = 32,16,8,4,2,1 (l < off);
@@ -43,6 +46,7 @@ BM25_K = 1.2                   # fastembed Qdrant/bm25 defaults              (a-
 BM25_B = 0.75
 BM25_AVG_LEN = 256.0
 SPARSE_IDF = False             # collection has no sparse modifier           (a-1/a-6)
+SPARSE_FIX_BITS = 40           # sparse scores: order-independent fixed-point sum (see sparse_scores)
 
 F32 = np.float32
 FLT_EPSILON = F32(1.1920929e-07)
@@ -270,23 +274,25 @@ class OracleIndex:
         return topk(s, np.arange(self.n), limit)
 
     def sparse_scores(self, q_idx, q_val):
-        """score(d) = sum over query terms (ascending term id, stable) of
-        q_t * d_t in fp32 (unfused mul, add); only docs sharing >= 1 term are
-        candidates; IDF-free (a-6).  Returns (touched_doc_ids, scores)."""
+        """score(d) = sum over the query's terms of q_t * d_t; only docs sharing >= 1
+        term are candidates; IDF-free (a-6).  Each product is exact in fp64, scaled by
+        2^SPARSE_FIX_BITS and rounded (ties to even) to int64; the integer sum is converted once to
+        fp32 (so the result does not depend on the order of the terms).
+        Returns (touched_doc_ids, scores)."""
         q_idx = np.asarray(q_idx, dtype=np.int64)
         q_val = np.asarray(q_val, dtype=F32)
-        order = np.argsort(q_idx, kind="stable")
-        q_idx, q_val = q_idx[order], q_val[order]
-        acc = np.zeros(self.n, dtype=F32)
+        acc = np.zeros(self.n, dtype=np.int64)
         touched = np.zeros(self.n, dtype=bool)
         doc_of = np.repeat(np.arange(self.n), np.diff(self.sp_indptr))
+        scale = float(1 << SPARSE_FIX_BITS)
         for t, w in zip(q_idx, q_val):
             m = self.sp_idx == t
             d = doc_of[m]
-            acc[d] = acc[d] + (w * self.sp_val[m]).astype(F32)
+            fx = np.rint((np.float64(w) * self.sp_val[m].astype(np.float64)) * scale).astype(np.int64)
+            np.add.at(acc, d, fx)
             touched[d] = True
         ids = np.nonzero(touched)[0]
-        return ids, acc[ids]
+        return ids, (acc[ids].astype(F32) * F32(2.0 ** -SPARSE_FIX_BITS)).astype(F32)
 
     def search_sparse(self, q_idx, q_val, limit: int):
         """Prefetch(query=SparseVector, using="sparse", limit) (qdrant_handler.py:347-354)."""

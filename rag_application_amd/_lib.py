@@ -81,10 +81,11 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise HxError(f"{LIB_PATH} is missing: run `python -m rag_application_amd.build` "
+        path = os.environ.get("HX_LIB_PATH") or LIB_PATH   # override: diagnostic builds (scripts/) only
+        if not os.path.exists(path):
+            raise HxError(f"{path} is missing: run `python -m rag_application_amd.build` "
                           "(the engine has no CPU fallback)")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, args in _SIGS.items():
             f = getattr(l, name)
             f.argtypes = args

@@ -115,7 +115,8 @@ void launch_prep_queries_i8(const float* q_raw, int q_dim, int B, int Bpad, int 
                             float* rinv_q, hipStream_t st);
 
 // ---- sparse.hip --------------------------------------------------------------
-constexpr int SEG_DOCS = 8192;        // docs per index segment (LDS accumulator = 32 KiB)
+constexpr int SEG_DOCS = 8192;        // docs per index segment (LDS accumulator: 8 B per doc = 64 KiB)
+constexpr int SP_CAND = 8192;         // per-workgroup candidate buffer (keys, global memory)
 struct SpHashEntry {
   uint64_t key;            // (segment << 31) | term ; ~0 = empty
   uint32_t off, len;
@@ -139,6 +140,10 @@ struct SparseQueryArgs {
   int limit;
   uint64_t* out;               // [B x parts x limit] sorted best-first per (query, part)
   int* out_cnt;                // [B x parts]
+  unsigned long long* stat_postings;  // optional: postings visited (profile)
+  uint64_t* cand;              // [B x parts x SP_CAND] workgroup-private candidate buffers
+  unsigned long long* park;    // [B x parts x SEG_DOCS/2] scratch for the rare two-pass harvest
+  int* q_order;                // [B] scratch: queries by descending term count (may be NULL)
 };
 void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st);
 

@@ -376,3 +376,45 @@ def test_golden_fixtures_through_the_abi(eng, torch_mod, synth_tables):
     chk("h1", *ix.hybrid_query(Qd, *tq, eng.make_params(dict(P_MCP, dense_limit=100, sparse_limit=100, final_limit=10),
                                                         mode=eng.HX_MODE_H1)))
     ix.close()
+
+
+def test_sparse_cold_paths(eng, torch_mod):
+    """Sparse scoring beyond the pipelined fast path: a term held by EVERY document with
+    equal weights (runs longer than a workgroup, 8192 tied survivors per segment: the
+    two-pass harvest and the id-ascending tie rule), queries with more than 12 terms (the
+    generic loop), negative weights, a term nobody holds, an empty query."""
+    n, dim = 20000, 64
+    rng = np.random.default_rng(9)
+    vocab = 300
+    indptr, idx, val = [0], [], []
+    for d in range(n):
+        terms = rng.choice(vocab, size=int(rng.integers(1, 30)), replace=False) + 10
+        w = rng.uniform(-1.0, 2.0, len(terms)).astype(np.float32)
+        idx.extend([7] + terms.tolist())            # term 7 is in every document, weight 1.0
+        val.extend([1.0] + w.tolist())
+        indptr.append(len(idx))
+    indptr, idx, val = np.asarray(indptr, np.int64), np.asarray(idx, np.int64), np.asarray(val, np.float32)
+    X = O.synth_dense(31, 0, n, dim)
+    ora = O.OracleIndex(dim, ())
+    ora.add(X, indptr, idx, val)
+    ora.finalize()
+    ix = eng.HxIndex(dim, ())
+    ix.add(X, indptr, idx.astype(np.int32), val)
+    queries = [([7], [2.0]),                                             # all docs tie
+               ([7, 11, 12], [1.0, 0.5, -0.25]),
+               (list(range(10, 40)), rng.uniform(0.1, 2.0, 30).tolist()),  # 30 terms: generic path
+               ([5000], [1.0]),                                          # absent term
+               ([], []),                                                 # empty query
+               ([11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53], [1.0] * 12),
+               ([7] + list(range(100, 112)), [0.001] + [1.0] * 12)]      # 13 terms
+    qip = np.cumsum([0] + [len(q[0]) for q in queries]).astype(np.int64)
+    qix = np.concatenate([np.asarray(q[0], np.int32) for q in queries])
+    qv = np.concatenate([np.asarray(q[1], np.float32) for q in queries])
+    for limit in (10, 100, 1000):
+        keys, cnt = ix.search_sparse(torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qix).cuda(),
+                                     torch_mod.from_numpy(qv).cuda(), limit)
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b, (ti, tv) in enumerate(queries):
+            es, ei = ora.search_sparse(np.asarray(ti, np.int64), np.asarray(tv, np.float32), limit)
+            assert_list_equal(s[b], i[b], c[b], es, ei, f"sparse cold b={b} L={limit}")
+    ix.close()
