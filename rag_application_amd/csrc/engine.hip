@@ -46,7 +46,7 @@ enum WsSlot {
   WS_NFAIL, WS_QSEL, WS_FB_KEYS, WS_FB_CNT, WS_FB_INCNT, WS_SP_PARTS, WS_SP_PCNT, WS_RAW, WS_RS_TMP,
   WS_T_A, WS_T_ACNT, WS_T_B, WS_T_BCNT, WS_T_C, WS_T_CCNT, WS_T_D, WS_T_DCNT, WS_T_E, WS_T_ECNT,
   WS_T_F, WS_T_FCNT, WS_T_G, WS_T_GCNT, WS_H_QD, WS_H_QIP, WS_H_QIX, WS_H_QV, WS_H_OUT, WS_H_OCNT,
-  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC
+  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER
 };
 
 template <typename T>
@@ -91,6 +91,7 @@ struct hx_index {
   bool prof = false;
   std::vector<ProfRec> prof_recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  unsigned long long* sp_counter = nullptr;   // postings visited by k_sparse_score while profiling
 
   void set_device() const { HX_HIP(hipSetDevice(device)); }
 };
@@ -502,6 +503,17 @@ static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q
   a.limit = L;
   a.out = pk;
   a.out_cnt = pc;
+  a.cand = (uint64_t*)h->ws.get(WS_SP_CAND, (size_t)B * parts * SP_CAND * 8);
+  a.park = (unsigned long long*)h->ws.get(WS_SP_PARK, (size_t)B * parts * (SEG_DOCS / 2) * 8);
+  a.q_order = (int*)h->ws.get(WS_SP_ORDER, (size_t)B * 4);
+  a.stat_postings = nullptr;
+  if (h->prof) {
+    if (!h->sp_counter) {
+      HX_HIP(hipMalloc((void**)&h->sp_counter, 8));
+      HX_HIP(hipMemset(h->sp_counter, 0, 8));
+    }
+    a.stat_postings = h->sp_counter;
+  }
   {
     ProfScope ps(h, st, 2, 0.0, 0.0);
     launch_sparse_score(a, st);
@@ -687,7 +699,7 @@ int hx_destroy(hx_index* h) {
   (void)hipDeviceSynchronize();
   free_sparse_index(h);
   void* ptrs[] = {h->dense, h->dense_h, h->q8, h->q8_rinv, h->pre[0], h->pre[1], h->pre[2], h->pre_h0,
-                  h->sp_indptr, h->sp_idx, h->sp_val};
+                  h->sp_indptr, h->sp_idx, h->sp_val, h->sp_counter};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->ws.release();
@@ -1034,6 +1046,12 @@ int hx_profile_read(hx_index* h, hx_prof* out) {
     h->prof_pool.emplace_back(r.a, r.b);
   }
   h->prof_recs.clear();
+  if (h->sp_counter) {
+    unsigned long long np = 0;
+    HX_HIP(hipMemcpy(&np, h->sp_counter, 8, hipMemcpyDeviceToHost));
+    HX_HIP(hipMemset(h->sp_counter, 0, 8));
+    out->bytes[2] = (double)np * 6.0;   // u16 doc + f32 weight per posting visited
+  }
   HX_CATCH
 }
 
