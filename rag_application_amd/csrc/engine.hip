@@ -206,6 +206,9 @@ static Geometry geometry(int L, bool approx, bool safe) {
   return g;
 }
 
+// query-tile width of the scan kernel for a batch of B queries
+static int scan_bn(int B) { return B <= 32 ? 32 : (B <= 64 ? 64 : (B <= 128 ? 128 : 256)); }
+
 struct MatrixRef {
   const float* m32;
   const _Float16* m16;
@@ -384,7 +387,7 @@ static void search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
   if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
   const int wo = 1000 * level;  // workspace slots of this level
   const MatrixRef m = pick_matrix(h, prefix);
-  const int bn = B <= 32 ? 32 : (B <= 64 ? 64 : 128);
+  const int bn = scan_bn(B);
   const int Bpad = (int)round_up(B, bn);
   float* qn = (float*)h->ws.get(WS_QN + wo, (size_t)B * m.dpad * 4);
   _Float16* qh = (_Float16*)h->ws.get(WS_QH + wo, (size_t)Bpad * m.dpad * 2);
@@ -444,7 +447,7 @@ static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* o
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
   const int wo = 1000 * level;
-  const int bn = B <= 32 ? 32 : (B <= 64 ? 64 : 128);
+  const int bn = scan_bn(B);
   const int Bpad = (int)round_up(B, bn);
   int8_t* q8 = (int8_t*)h->ws.get(WS_Q8 + wo, (size_t)Bpad * h->dim_pad8);
   float* rq = (float*)h->ws.get(WS_RINVQ + wo, (size_t)Bpad * 4);

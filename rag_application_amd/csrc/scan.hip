@@ -38,20 +38,23 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KIND, int BN, int NSTAGE>
-__global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
-  constexpr int BM = 128;
-  constexpr int WN = (BN >= 64) ? 2 : 1;
-  constexpr int WM = 4 / WN;
+// Tile shapes: 256 x 256 with 8 waves (each 128 x 64: 4 x 2 MFMA tiles, 0.75 LDS fragment
+// reads per MFMA, 128 KiB of LDS, one workgroup per CU) for large batches; 128 x {128,64,32}
+// with 4 waves (two workgroups per CU) for small ones.
+template <int KIND, int BM, int BN, int NSTAGE>
+__global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
+  constexpr int NW = BM / 32;                       // waves: 8 or 4
+  constexpr int WN = BN >= 256 ? 4 : (BN >= 64 ? 2 : 1);
+  constexpr int WM = NW / WN;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
   constexpr int A_BYTES = BM * 128;
   constexpr int B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int A_LPW = BM / 8 / 4;  // 1-KiB pieces per wave
-  constexpr int B_LPW = BN / 8 / 4;
+  constexpr int A_LPW = BM / 8 / NW;  // 1-KiB pieces per wave
+  constexpr int B_LPW = BN / 8 / NW;
   constexpr int LPW = A_LPW + B_LPW;
-  static_assert(B_LPW >= 1, "BN >= 32");
+  static_assert(B_LPW >= 1, "BN >= 8 * waves");
 
   __shared__ __attribute__((aligned(1024))) uint8_t lds[NSTAGE * STAGE];
 
@@ -60,6 +63,18 @@ __global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
+
+  // kernel-argument pointers inside a struct are generic to hipcc: make them provably global, or the
+  // epilogue's accesses become FLAT instructions whose waits also drain the LDS-DMA queue
+  typedef __attribute__((address_space(1))) const float GF;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) const f32x4 GF4;
+  GF* g_tau = (GF*)a.tau;
+  GF* g_rinv_q = (GF*)a.rinv_q;
+  GF* g_rinv_x = (GF*)a.rinv_x;
+  auto* g_cnt = (__attribute__((address_space(1))) int*)a.cnt;
+  auto* g_ovf = (__attribute__((address_space(1))) int*)a.overflow;
+  auto* g_cand = (__attribute__((address_space(1))) uint64_t*)a.cand;
 
   const int KT = (int)(a.row_bytes >> 7);
   const int64_t n_rows = a.row_end - a.row_begin;
@@ -80,40 +95,53 @@ __global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
   const int64_t total_steps = (int64_t)my_items * KT;
 
   // ---- load cursor -----------------------------------------------------------
+  // Per tile, each lane keeps the byte offset of its 16-byte slot in every 1-KiB piece it
+  // loads (rows past the end of the scan range are clamped to the last row); per k-step
+  // the source is tile base + lane offset + 128*kt: two 64-bit adds per load.
   int lj = i0;
   int l_kt = 0;
-  int l_rt = (int)(lj / nq) * 8 + xcd, l_qt = (int)(lj % nq);
   int64_t l_step = 0;
+  const int rin = lane >> 3, pslot = lane & 7;
+  const uint8_t* a_tile = nullptr;
+  const uint8_t* q_tile = nullptr;
+  int64_t a_off[A_LPW], b_off[B_LPW];
+  auto set_tile = [&]() {
+    const int rt = (lj / nq) * 8 + xcd, qt = lj % nq;
+    const int64_t row0 = a.row_begin + (int64_t)rt * BM;
+    const int64_t left = a.row_end - row0;             // >= 1 for every tile a block is given
+    a_tile = a.A + row0 * a.row_bytes;
+    q_tile = a.Q + (int64_t)qt * BN * a.row_bytes;
+#pragma unroll
+    for (int c = 0; c < A_LPW; ++c) {
+      const int trow = (wave + NW * c) * 8 + rin;
+      const int64_t erow = trow < left ? trow : left - 1;
+      a_off[c] = erow * a.row_bytes + ((pslot ^ ((trow >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int c = 0; c < B_LPW; ++c) {
+      const int trow = (wave + NW * c) * 8 + rin;
+      b_off[c] = (int64_t)trow * a.row_bytes + ((pslot ^ ((trow >> 1) & 7)) << 4);
+    }
+  };
+  set_tile();
 
   auto issue_load = [&]() {
     const int st = (int)(l_step % NSTAGE);
     uint8_t* sbase = lds + st * STAGE;
-    const int rin = lane >> 3, pslot = lane & 7;
+    const int64_t koff = (int64_t)l_kt << 7;
 #pragma unroll
-    for (int c = 0; c < A_LPW; ++c) {
-      const int piece = wave + 4 * c;
-      const int trow = piece * 8 + rin;
-      int64_t grow = a.row_begin + (int64_t)l_rt * BM + trow;
-      grow = grow < a.row_end ? grow : a.row_end - 1;
-      const int lslot = pslot ^ ((trow >> 1) & 7);
-      const uint8_t* src = a.A + grow * a.row_bytes + ((int64_t)l_kt << 7) + (lslot << 4);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sbase + piece * 1024), 16, 0, 0);
-    }
+    for (int c = 0; c < A_LPW; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_tile + a_off[c] + koff), LDS_PTR(sbase + (wave + NW * c) * 1024), 16,
+                                       0, 0);
 #pragma unroll
-    for (int c = 0; c < B_LPW; ++c) {
-      const int piece = wave + 4 * c;
-      const int trow = piece * 8 + rin;
-      const int64_t qrow = (int64_t)l_qt * BN + trow;
-      const int lslot = pslot ^ ((trow >> 1) & 7);
-      const uint8_t* src = a.Q + qrow * a.row_bytes + ((int64_t)l_kt << 7) + (lslot << 4);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sbase + A_BYTES + piece * 1024), 16, 0, 0);
-    }
+    for (int c = 0; c < B_LPW; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(q_tile + b_off[c] + koff),
+                                       LDS_PTR(sbase + A_BYTES + (wave + NW * c) * 1024), 16, 0, 0);
     ++l_step;
     if (++l_kt == KT) {
       l_kt = 0;
       lj += per_xcd;
-      l_rt = (int)(lj / nq) * 8 + xcd;
-      l_qt = (int)(lj % nq);
+      if (l_step < total_steps) set_tile();
     }
   };
 
@@ -146,31 +174,35 @@ __global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
 
     const uint8_t* As = lds + (int)(s % NSTAGE) * STAGE;
     const uint8_t* Bs = As + A_BYTES;
+    // all fragments of the k-step first (16-byte LDS reads, conflict free), then the MFMAs:
+    // hipcc interleaves them behind counted lgkmcnt waits
+    half8 af[4][TM], bf[4][TN];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      half8 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * (TM * 32) + i * 32 + r;
-        af[i] = *(const half8*)(As + row * 128 + ((((kk << 1) | h) ^ ((row >> 1) & 7)) << 4));
+        af[kk][i] = *(const half8*)(As + row * 128 + ((((kk << 1) | h) ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * (TN * 32) + j * 32 + r;
-        bf[j] = *(const half8*)(Bs + row * 128 + ((((kk << 1) | h) ^ ((row >> 1) & 7)) << 4));
+        bf[kk][j] = *(const half8*)(Bs + row * 128 + ((((kk << 1) | h) ^ ((row >> 1) & 7)) << 4));
       }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if constexpr (KIND == KIND_F16) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
           } else {
-            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
-                __builtin_bit_cast(i32x4, af[i]), __builtin_bit_cast(i32x4, bf[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, af[kk][i]),
+                                                              __builtin_bit_cast(i32x4, bf[kk][j]), acc[i][j], 0, 0, 0);
           }
         }
-    }
 
     if (++c_kt == KT) {
       // ---- epilogue: threshold filter + append ----------------------------------
@@ -181,9 +213,9 @@ __global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
       for (int j = 0; j < TN; ++j) {
         const int q = qt * BN + wn * (TN * 32) + j * 32 + r;
         const bool qok = q < a.B;
-        const float tau = qok ? a.tau[q] : __builtin_inff();
+        const float tau = qok ? g_tau[q] : __builtin_inff();
         float rq = 0.f;
-        if constexpr (KIND == KIND_I8) rq = qok ? a.rinv_q[q] : 0.f;
+        if constexpr (KIND == KIND_I8) rq = qok ? g_rinv_q[q] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int64_t row0 = a.row_begin + (int64_t)rt * BM + wm * (TM * 32) + i * 32 + 4 * h;
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               // rows row0+8g .. +3 ; rinv_x is padded past n_rows so this never faults
-              const float4 rx = *(const float4*)(a.rinv_x + row0 + 8 * g);
+              const f32x4 rx = *(const GF4*)(g_rinv_x + row0 + 8 * g);
               sc[4 * g + 0] = ((float)acc[i][j][4 * g + 0] * rx.x) * rq;
               sc[4 * g + 1] = ((float)acc[i][j][4 * g + 1] * rx.y) * rq;
               sc[4 * g + 2] = ((float)acc[i][j][4 * g + 2] * rx.z) * rq;
@@ -210,11 +242,11 @@ __global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
             for (int e = 0; e < 16; ++e) {
               const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
               if (sc[e] >= tau && row < a.row_end) {
-                const int pos = atomicAdd(a.cnt + q, 1);
+                const int pos = __hip_atomic_fetch_add(g_cnt + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (pos < a.cap)
-                  a.cand[(int64_t)q * a.cap + pos] = make_key(sc[e], (uint32_t)(a.id_base + row));
+                  g_cand[(int64_t)q * a.cap + pos] = make_key(sc[e], (uint32_t)(a.id_base + row));
                 else
-                  a.overflow[q] = 1;
+                  g_ovf[q] = 1;
               }
             }
           }
@@ -226,27 +258,30 @@ __global__ __launch_bounds__(256, 2) void k_scan(ScanArgs a) {
   }
 }
 
-template <int KIND, int BN, int NSTAGE>
-static void launch(const ScanArgs& a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((k_scan<KIND, BN, NSTAGE>), dim3(grid), dim3(256), 0, st, a);
+template <int KIND, int BM, int BN, int NSTAGE>
+static void launch(const ScanArgs& a, int64_t tiles, hipStream_t st) {
+  constexpr int per_cu = BM == 256 ? 1 : 2;
+  int64_t g = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+  g = (g + 7) / 8 * 8;  // whole XCD groups; blocks without items exit at once
+  hipLaunchKernelGGL((k_scan<KIND, BM, BN, NSTAGE>), dim3((unsigned)g), dim3(BM * 2), 0, st, a);
 }
 
 void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st) {
   const int64_t n_rows = a.row_end - a.row_begin;
   if (n_rows <= 0 || a.B <= 0) return;
   HX_CHECK((a.row_bytes & 127) == 0, "scan: row_bytes must be a multiple of 128");
-  const int64_t tiles = (n_rows + 127) / 128 * a.nq_tiles;
-  int64_t g = tiles < 512 ? tiles : 512;
-  g = (g + 7) / 8 * 8;  // whole XCD groups; blocks without items exit at once
-  const int grid = (int)g;
+  const int bm = bn == 256 ? 256 : 128;
+  const int64_t tiles = (n_rows + bm - 1) / bm * a.nq_tiles;
   if (kind == KIND_F16) {
-    if (bn == 128) launch<KIND_F16, 128, 2>(a, grid, st);
-    else if (bn == 64) launch<KIND_F16, 64, 3>(a, grid, st);
-    else launch<KIND_F16, 32, 3>(a, grid, st);
+    if (bn == 256) launch<KIND_F16, 256, 256, 2>(a, tiles, st);
+    else if (bn == 128) launch<KIND_F16, 128, 128, 2>(a, tiles, st);
+    else if (bn == 64) launch<KIND_F16, 128, 64, 3>(a, tiles, st);
+    else launch<KIND_F16, 128, 32, 3>(a, tiles, st);
   } else {
-    if (bn == 128) launch<KIND_I8, 128, 2>(a, grid, st);
-    else if (bn == 64) launch<KIND_I8, 64, 3>(a, grid, st);
-    else launch<KIND_I8, 32, 3>(a, grid, st);
+    if (bn == 256) launch<KIND_I8, 256, 256, 2>(a, tiles, st);
+    else if (bn == 128) launch<KIND_I8, 128, 128, 2>(a, tiles, st);
+    else if (bn == 64) launch<KIND_I8, 128, 64, 3>(a, tiles, st);
+    else launch<KIND_I8, 128, 32, 3>(a, tiles, st);
   }
   HX_HIP(hipGetLastError());
 }
