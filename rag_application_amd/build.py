@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libhx.so")
-SOURCES = ["scan.hip", "select.hip", "prep.hip", "sparse.hip", "spbuild.hip", "engine.hip"]
+SOURCES = ["scan.hip", "scan8.hip", "select.hip", "prep.hip", "sparse.hip", "spbuild.hip", "engine.hip"]
 HEADERS = ["hx_common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "hx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function"]

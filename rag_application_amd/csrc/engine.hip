@@ -46,7 +46,7 @@ enum WsSlot {
   WS_NFAIL, WS_QSEL, WS_FB_KEYS, WS_FB_CNT, WS_FB_INCNT, WS_SP_PARTS, WS_SP_PCNT, WS_RAW, WS_RS_TMP,
   WS_T_A, WS_T_ACNT, WS_T_B, WS_T_BCNT, WS_T_C, WS_T_CCNT, WS_T_D, WS_T_DCNT, WS_T_E, WS_T_ECNT,
   WS_T_F, WS_T_FCNT, WS_T_G, WS_T_GCNT, WS_H_QD, WS_H_QIP, WS_H_QIX, WS_H_QV, WS_H_OUT, WS_H_OCNT,
-  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER
+  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT
 };
 
 template <typename T>
@@ -276,10 +276,19 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   a.id_base = h->id_base;
   a.rinv_x = h->q8_rinv;
   a.rinv_q = rinv_q;
+  uint4* hitlog = nullptr;
+  int* hitcnt = nullptr;
+  if (bn == 256) {   // per-wave append logs of the 256 x 256 kernel (scan8.hip)
+    hitlog = (uint4*)h->ws.get(WS_HITLOG, (size_t)SCAN8_WAVES * SCAN8_LOGCAP * sizeof(uint4));
+    hitcnt = (int*)h->ws.get(WS_HITCNT, (size_t)SCAN8_WAVES * 4);
+  }
+  a.hitcnt = hitcnt;
+  a.logcap = SCAN8_LOGCAP;
   int64_t r0 = 0, r1 = std::min<int64_t>(h->n, g.C);
   while (r0 < h->n) {
     a.row_begin = r0;
     a.row_end = r1;
+    a.hitlog = r0 > 0 ? hitlog : nullptr;   // the first chunk passes every row: atomic-append kernel
     {
       const double rows = (double)(r1 - r0);
       const double elems = kind == KIND_F16 ? (double)row_bytes / 2.0 : (double)row_bytes;

@@ -29,8 +29,19 @@ struct ScanArgs {
   int64_t id_base;
   const float* rinv_x;     // i8: 1/||x|| per local row (padded)
   const float* rinv_q;     // i8: 1/||q|| per query (padded)
+  // scan8 only: per-wave append logs.  A passing (key, query) is stored -- fire and forget -- at
+  // hitlog[wave * logcap + i]; launch_scatter_log moves the logs into cand/cnt afterwards.
+  // hitlog == NULL (or a launch expected to pass most rows) selects the atomic-append kernel.
+  uint4* hitlog;           // [SCAN8_WAVES x logcap] {key lo, key hi, query, 0}
+  int* hitcnt;             // [SCAN8_WAVES] entries written (may exceed logcap: the rest set overflow[q])
+  int logcap;
 };
+constexpr int SCAN8_WAVES = 256 * 8;   // waves of the largest scan8 grid
+constexpr int SCAN8_LOGCAP = 8192;
 void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st);
+// scan8.hip: the 256 x 256 staggered-phase kernel behind launch_scan for large batches
+bool scan8_usable(const ScanArgs& a, int bn);
+void launch_scan8(const ScanArgs& a, int kind, hipStream_t st);   // includes the log scatter
 
 // ---- select.hip --------------------------------------------------------------
 // Sort each query's buffer (first min(cnt, stride) keys) best-first, optionally drop

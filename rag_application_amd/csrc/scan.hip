@@ -270,6 +270,7 @@ void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st) {
   const int64_t n_rows = a.row_end - a.row_begin;
   if (n_rows <= 0 || a.B <= 0) return;
   HX_CHECK((a.row_bytes & 127) == 0, "scan: row_bytes must be a multiple of 128");
+  if (scan8_usable(a, bn)) return launch_scan8(a, kind, st);
   const int bm = bn == 256 ? 256 : 128;
   const int64_t tiles = (n_rows + bm - 1) / bm * a.nq_tiles;
   if (kind == KIND_F16) {

@@ -1,0 +1,428 @@
+// K3/K5 for large batches -- the whole-collection scan S = X . Q^T as a 256 x 256 tile
+// per 512-thread workgroup, software-pipelined in half-tile phases with the two wave
+// groups of the workgroup staggered by half a phase.
+//
+// Same contract as scan.hip (reference: Prefetch(query=..., using="dense"|"quantized",
+// limit=...) of app/core/vector_store/qdrant/qdrant_handler.py:327-339, "rank the whole
+// collection by cosine"); this file only changes HOW the tile is computed.
+//
+// Geometry.  8 waves as 2 (rows) x 4 (queries); a wave owns 128 rows x 64 queries as four
+// quadrants C[ha][hb] of 64 x 32 (two 32x32 MFMA tiles each).  A k-tile is 128 bytes of
+// every row (64 halves / 128 int8).  The operands of one k-tile travel as four HALF-TILES
+// of 128 rows x 128 B = 16 KiB:
+//     A0, A1 : corpus rows  {wm*128 + h*64 + i}   (the h-th 64 rows of both wave rows)
+//     B0, B1 : query rows   {wn*64  + h*32 + j}   (the h-th 32 queries of all four wave columns)
+// Each half-tile is two 1-KiB global_load_lds pieces per wave (16 B per lane, lane-linear
+// LDS image, 16-byte-slot XOR swizzle applied to the SOURCE address and again on the
+// ds_read_b128 address -- conflict free, see scan.hip).
+//
+// Schedule.  Stream order of half-tiles: g = 4*T + {A0, B0, B1, A1}; slot = g mod 8
+// (8 x 16 KiB ring).  Phase p of k-tile T (P = 4*T + p):
+//     L segment : ds_read the fragments this phase needs, issue the two loads of
+//                 half-tile g = P + 6, s_waitcnt vmcnt(6)   (all but the 3 youngest done)
+//     barrier
+//     M segment : 8 MFMAs -- quadrant C00 (A0,B0), C01 (A0,B1), C11 (A1,B1), C10 (A1,B0)
+//     barrier
+//   reads: p0 A0(T) | p1 B1(T) | p2 A1(T) | p3 B0(T+1)   (B0 stays in registers for 4 phases)
+// RAW: a half-tile read in phase P+1 has g <= P+3, retired by every wave's vmcnt(6) in
+// phase P ahead of a barrier the reader passes.  WAR: half-tile g+8 is issued in phase
+// g+2 or later, its slot's last ds_read is in phase <= g (two phases = two barriers apart).
+// Waves 4..7 (wm = 1) run one barrier behind waves 0..3, so on every SIMD one wave is in
+// its M segment while its partner is in its L segment: the matrix pipe never waits for
+// LDS reads or load issue.  Per-query thresholds live in LDS (no VGPR-destination global
+// loads inside the pipeline: those would make hipcc drain the LDS-DMA queue).
+//
+// Appends.  A returning atomic on the per-query counter stalls the wave -- and through the
+// barriers its whole workgroup -- for a memory round trip per passing score (measured: +34 %
+// kernel time at 1,200 passes per query).  Instead every wave owns a log in global memory and
+// writes (key, query) with plain stores at a scalar position it keeps itself; k_scatter_log
+// moves the logs into the per-query candidate buffers after the scan.
+#include <stdlib.h>
+#include <type_traits>
+#include "hx_common.hpp"
+#include "kernels.hpp"
+
+namespace hx {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+constexpr int S8_HT = 16384;       // half-tile bytes
+constexpr int S8_MAXQ = 4096;      // queries whose thresholds fit the LDS table
+
+template <int KIND, int DBG>
+__global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
+  constexpr int AUX = (KIND == KIND_I8 ? 2 : 1) * S8_MAXQ * 4;
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[8 * S8_HT + AUX];
+  float* lds_tau = (float*)(lds + 8 * S8_HT);
+  float* lds_rq = lds_tau + S8_MAXQ;   // I8 only
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 31, hh = lane >> 5;
+
+  typedef __attribute__((address_space(1))) const float GF;
+  typedef __attribute__((address_space(1))) const f32x4 GF4;
+  GF* g_tau = (GF*)a.tau;
+  GF* g_rinv_q = (GF*)a.rinv_q;
+  GF* g_rinv_x = (GF*)a.rinv_x;
+  auto* g_ovf = (__attribute__((address_space(1))) int*)a.overflow;
+
+  const int KT = (int)(a.row_bytes >> 7);
+  const int64_t n_rows = a.row_end - a.row_begin;
+  const int n_row_tiles = (int)((n_rows + 255) >> 8);
+  const int nq = a.nq_tiles;
+
+  // XCD-aware tile walk (as scan.hip): XCD x owns row tiles == x (mod 8), query tile fastest
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7;
+  const int per_xcd = G >> 3;
+  const int my_rt = (n_row_tiles - xcd + 7) >> 3;
+  const int items_x = my_rt * nq;
+  const int i0 = blockIdx.x >> 3;
+  if (i0 >= items_x) {
+    if (lane == 0) a.hitcnt[blockIdx.x * 8 + wave] = 0;
+    return;
+  }
+  const int my_items = (items_x - i0 + per_xcd - 1) / per_xcd;
+  const int total_T = my_items * KT;   // k-tiles of this block (launch_scan8 bounds it below 2^31)
+
+  // thresholds (and int8 query scales) of every query -> LDS, +inf for the padding
+  const int Bpad = nq * 256;
+  for (int q = tid; q < Bpad; q += 512) {
+    lds_tau[q] = q < a.B ? g_tau[q] : __builtin_inff();
+    if constexpr (KIND == KIND_I8) lds_rq[q] = q < a.B ? g_rinv_q[q] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- per-lane constants ---------------------------------------------------------
+  // source byte offsets of this lane's 16-byte slot in each (half-tile kind, piece)
+  uint32_t offA[2][2], offB[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int rr = (wave + 8 * c) * 8 + (lane >> 3);          // row of the half-tile image
+    const uint32_t sl = (uint32_t)(((lane & 7) ^ ((rr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      offA[h][c] = (uint32_t)((rr >> 6) * 128 + h * 64 + (rr & 63)) * (uint32_t)a.row_bytes + sl;
+      offB[h][c] = (uint32_t)((rr >> 5) * 64 + h * 32 + (rr & 31)) * (uint32_t)a.row_bytes + sl;
+    }
+  }
+  // fragment read offsets inside a half-tile: row*128 + ((kk*2 + hh) ^ swz)*16
+  const int swz = (r >> 1) & 7;
+  uint32_t rdA[4], rdB[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const uint32_t s = (uint32_t)((((kk << 1) | hh) ^ swz) << 4);
+    rdA[kk] = (uint32_t)(wm * 64 + r) * 128 + s;     // + mt*4096
+    rdB[kk] = (uint32_t)(wn * 32 + r) * 128 + s;
+  }
+
+  // ---- load cursors: k-tile T+1 (c1) and T+2 (c2) -----------------------------------
+  struct Cur {
+    const uint8_t* a;
+    const uint8_t* q;
+    int koff;
+  };
+  int lj = i0;          // item of cursor c2
+  auto tile_ptrs = [&](int j, Cur& c) __attribute__((always_inline)) {
+    const int d = __builtin_amdgcn_readfirstlane(j / nq);   // keep the cursor in scalar registers
+    const int rt = DBG == 1 ? 0 : d * 8 + xcd, qt = j - d * nq;
+    c.a = a.A + (a.row_begin + (int64_t)rt * 256) * a.row_bytes;
+    c.q = a.Q + (int64_t)qt * 256 * a.row_bytes;
+  };
+  auto advance = [&](Cur& c) __attribute__((always_inline)) {
+    c.koff += 128;
+    if (c.koff == (int)a.row_bytes) {
+      c.koff = 0;
+      if (lj + per_xcd < items_x) {   // past the last item: keep re-loading it (never read)
+        lj += per_xcd;
+        tile_ptrs(lj, c);
+      }
+    }
+  };
+  bool in_loop = false;
+  auto stage = [&](const uint8_t* base, int koff, const uint32_t (&off)[2], int slot) __attribute__((always_inline)) {
+    if (DBG == 2 && in_loop) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(base + koff + off[c]),
+                                       LDS_PTR(lds + slot * S8_HT + (wave + 8 * c) * 1024), 16, 0, 0);
+  };
+
+  using frag_t = half8;
+  using acc_t = typename std::conditional<KIND == KIND_F16, f32x16, i32x16>::type;
+  acc_t acc[2][2][2];   // [ha][hb][mt]
+  frag_t af[2][4];      // current A half: [mt][kk]
+  frag_t bA[4], bB[4];  // query fragments: B0 / B1 alternate between the two sets
+
+  auto read_a = [&](int slot) __attribute__((always_inline)) {
+    const uint8_t* s = lds + slot * S8_HT;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) af[mt][kk] = *(const frag_t*)(s + rdA[kk] + mt * 4096);
+  };
+  auto read_b = [&](int slot, frag_t (&b)[4]) __attribute__((always_inline)) {
+    const uint8_t* s = lds + slot * S8_HT;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) b[kk] = *(const frag_t*)(s + rdB[kk]);
+  };
+
+  // ---- prologue: half-tiles g = 0..5 ---------------------------------------------------
+  Cur c1{}, c2{};
+  c2.koff = 0;
+  tile_ptrs(lj, c2);
+  stage(c2.a, c2.koff, offA[0], 0);
+  stage(c2.q, c2.koff, offB[0], 1);
+  stage(c2.q, c2.koff, offB[1], 2);
+  stage(c2.a, c2.koff, offA[1], 3);
+  advance(c2);                       // T = 1
+  stage(c2.a, c2.koff, offA[0], 4);
+  stage(c2.q, c2.koff, offB[0], 5);
+  c1 = c2;
+  advance(c2);                       // T = 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_b(1, bA);
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger
+
+  int cj = i0, c_kt = 0;
+  in_loop = true;
+
+  // quadrant epilogue: threshold filter; passing (key, query) pairs go to this wave's log
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  auto* g_log = (__attribute__((address_space(1))) u32x4*)a.hitlog +
+                (int64_t)(blockIdx.x * 8 + wave) * a.logcap;
+  int wpos = 0;   // entries this wave has logged (scalar)
+  auto filter = [&](int rt, int qt, int ha, int hb, acc_t (&c)[2]) __attribute__((always_inline)) {
+    const int q = qt * 256 + wn * 64 + hb * 32 + r;
+    const float tau = lds_tau[q];
+    const int64_t rowq = a.row_begin + (int64_t)rt * 256 + wm * 128 + ha * 64 + 4 * hh;
+    float sc[2][16];
+    if constexpr (KIND == KIND_F16) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[mt][e] = c[mt][e];
+    } else {
+      const float rq = lds_rq[q];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 rx = *(const GF4*)(g_rinv_x + rowq + mt * 32 + 8 * g);   // padded past n_rows
+          sc[mt][4 * g + 0] = ((float)c[mt][4 * g + 0] * rx.x) * rq;
+          sc[mt][4 * g + 1] = ((float)c[mt][4 * g + 1] * rx.y) * rq;
+          sc[mt][4 * g + 2] = ((float)c[mt][4 * g + 2] * rx.z) * rq;
+          sc[mt][4 * g + 3] = ((float)c[mt][4 * g + 3] * rx.w) * rq;
+        }
+    }
+    // maxima of the 8 groups of 4 consecutive rows, then of the quadrant: the common case (no
+    // lane reaches its threshold) leaves after ~20 VALU instructions
+    float gm[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        gm[mt][g] = __builtin_fmaxf(__builtin_fmaxf(sc[mt][4 * g], sc[mt][4 * g + 1]),
+                                    __builtin_fmaxf(sc[mt][4 * g + 2], sc[mt][4 * g + 3]));
+    const float m = __builtin_fmaxf(
+        __builtin_fmaxf(__builtin_fmaxf(gm[0][0], gm[0][1]), __builtin_fmaxf(gm[0][2], gm[0][3])),
+        __builtin_fmaxf(__builtin_fmaxf(gm[1][0], gm[1][1]), __builtin_fmaxf(gm[1][2], gm[1][3])));
+    if (__builtin_amdgcn_ballot_w64(m >= tau) == 0ull) return;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (__builtin_amdgcn_ballot_w64(gm[mt][g] >= tau) == 0ull) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t row = rowq + mt * 32 + 8 * g + i;
+          const float s = sc[mt][4 * g + i];
+          const bool hit = s >= tau && row < a.row_end;
+          const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
+          if (mask == 0ull) continue;
+          const int idx = wpos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          if (hit) {
+            if (idx < a.logcap) {
+              const uint64_t key = make_key(s, (uint32_t)(a.id_base + row));
+              g_log[idx] = u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)q, 0u};
+            } else {
+              g_ovf[q] = 1;
+            }
+          }
+          wpos += __builtin_popcountll(mask);
+        }
+      }
+  };
+
+  auto mma = [&](acc_t (&c)[2], const frag_t (&b)[4], bool first) __attribute__((always_inline)) {
+    if constexpr (DBG == 3) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        asm volatile("" ::"v"(b[kk]));
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) asm volatile("" ::"v"(af[mt][kk]));
+      }
+      if (first) { c[0] = acc_t{}; c[1] = acc_t{}; }
+      return;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if constexpr (KIND == KIND_F16) {
+          const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          c[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][kk], b[kk], (first && kk == 0) ? z : c[mt], 0, 0, 0);
+        } else {
+          const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          c[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, af[mt][kk]),
+                                                        __builtin_bit_cast(i32x4, b[kk]),
+                                                        (first && kk == 0) ? z : c[mt], 0, 0, 0);
+        }
+      }
+  };
+
+#define S8_L_END()                                   \
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   \
+  __builtin_amdgcn_sched_barrier(0);                 \
+  __builtin_amdgcn_s_barrier();                      \
+  __builtin_amdgcn_sched_barrier(0);                 \
+  __builtin_amdgcn_s_setprio(1);
+#define S8_M_END()                                   \
+  __builtin_amdgcn_s_setprio(0);                     \
+  __builtin_amdgcn_sched_barrier(0);                 \
+  __builtin_amdgcn_s_barrier();                      \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // one k-tile = four phases.  PAR = T & 1 (ring half and the B register set holding B0).
+  auto ktile = [&](auto par_c, auto first_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value;
+    constexpr int S0 = 4 * PAR, N0 = 4 * (1 - PAR);
+    frag_t(&b0)[4] = PAR ? bB : bA;
+    frag_t(&b1)[4] = PAR ? bA : bB;
+    const bool last = (c_kt == KT - 1);
+    int rt = 0, qt = 0;
+    if (last) {
+      const int d = __builtin_amdgcn_readfirstlane(cj / nq);
+      rt = d * 8 + xcd;
+      qt = cj - d * nq;
+    }
+
+    // phase 0: C00 += A0 . B0
+    read_a(S0 + 0);
+    stage(c1.q, c1.koff, offB[1], N0 + 2);
+    S8_L_END();
+    mma(acc[0][0], b0, FIRST);
+    if (last) filter(rt, qt, 0, 0, acc[0][0]);
+    S8_M_END();
+    // phase 1: C01 += A0 . B1
+    read_b(S0 + 2, b1);
+    stage(c1.a, c1.koff, offA[1], N0 + 3);
+    S8_L_END();
+    mma(acc[0][1], b1, FIRST);
+    if (last) filter(rt, qt, 0, 1, acc[0][1]);
+    S8_M_END();
+    // phase 2: C11 += A1 . B1
+    read_a(S0 + 3);
+    stage(c2.a, c2.koff, offA[0], S0 + 0);
+    S8_L_END();
+    mma(acc[1][1], b1, FIRST);
+    if (last) filter(rt, qt, 1, 1, acc[1][1]);
+    S8_M_END();
+    // phase 3: C10 += A1 . B0 ; B0 of the next k-tile replaces B1
+    read_b(N0 + 1, b1);
+    stage(c2.q, c2.koff, offB[0], S0 + 1);
+    S8_L_END();
+    mma(acc[1][0], b0, FIRST);
+    if (last) filter(rt, qt, 1, 0, acc[1][0]);
+    S8_M_END();
+
+    c1 = c2;
+    advance(c2);
+    c_kt = last ? 0 : c_kt + 1;
+    cj += last ? per_xcd : 0;
+  };
+  auto ktile_any = [&](auto par_c) __attribute__((always_inline)) {
+    if (c_kt == 0)
+      ktile(par_c, std::true_type{});
+    else
+      ktile(par_c, std::false_type{});
+  };
+
+  int T = 0;
+  for (; T + 1 < total_T; T += 2) {
+    ktile_any(std::integral_constant<int, 0>{});
+    ktile_any(std::integral_constant<int, 1>{});
+  }
+  if (T < total_T) ktile_any(std::integral_constant<int, 0>{});
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the never-read tail loads
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  if (lane == 0) a.hitcnt[blockIdx.x * 8 + wave] = wpos;
+#undef S8_L_END
+#undef S8_M_END
+}
+
+// one workgroup per wave log: entries -> the per-query candidate buffers (order is irrelevant,
+// k_compact sorts them)
+__global__ __launch_bounds__(256) void k_scatter_log(const uint4* __restrict__ log, const int* __restrict__ hitcnt,
+                                                     int logcap, uint64_t* __restrict__ cand, int* __restrict__ cnt,
+                                                     int* __restrict__ ovf, int cap) {
+  const int w = blockIdx.x;
+  int n = hitcnt[w];
+  n = n < logcap ? n : logcap;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint4 e = log[(int64_t)w * logcap + i];
+    const int q = (int)e.z;
+    const int pos = atomicAdd(cnt + q, 1);
+    if (pos < cap)
+      cand[(int64_t)q * cap + pos] = ((uint64_t)e.y << 32) | e.x;
+    else
+      ovf[q] = 1;
+  }
+}
+
+bool scan8_usable(const ScanArgs& a, int bn) {
+  return bn == 256 && a.hitlog != nullptr && a.B <= S8_MAXQ && (a.row_begin & 255) == 0 &&
+         a.row_bytes * 256 < (1ll << 31);
+}
+
+void launch_scan8(const ScanArgs& a, int kind, hipStream_t st) {
+  const int64_t n_rows = a.row_end - a.row_begin;
+  if (n_rows <= 0 || a.B <= 0) return;
+  HX_CHECK((a.row_bytes & 127) == 0, "scan: row_bytes must be a multiple of 128");
+  const int64_t tiles = (n_rows + 255) / 256 * a.nq_tiles;
+  HX_CHECK(tiles * (a.row_bytes >> 7) < (1ll << 31), "scan: launch too large");
+  HX_CHECK(a.hitlog && a.hitcnt && a.logcap > 0, "scan8: no hit log");
+  int64_t g = tiles < 256 ? tiles : 256;
+  g = (g + 7) / 8 * 8;
+#ifdef HX_SCAN_DBG
+  static const int dbg = getenv("HX_SCAN_DBG") ? atoi(getenv("HX_SCAN_DBG")) : 0;
+  if (kind == KIND_F16 && dbg == 1) hipLaunchKernelGGL((k_scan8<KIND_F16, 1>), dim3((unsigned)g), dim3(512), 0, st, a);
+  else if (kind == KIND_F16 && dbg == 2) hipLaunchKernelGGL((k_scan8<KIND_F16, 2>), dim3((unsigned)g), dim3(512), 0, st, a);
+  else if (kind == KIND_F16 && dbg == 3) hipLaunchKernelGGL((k_scan8<KIND_F16, 3>), dim3((unsigned)g), dim3(512), 0, st, a);
+  else
+#endif
+  if (kind == KIND_F16)
+    hipLaunchKernelGGL((k_scan8<KIND_F16, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_scan8<KIND_I8, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
+  HX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_scatter_log, dim3((unsigned)g * 8), dim3(256), 0, st, a.hitlog, a.hitcnt, a.logcap, a.cand,
+                     a.cnt, a.overflow, a.cap);
+  HX_HIP(hipGetLastError());
+}
+
+}  // namespace hx

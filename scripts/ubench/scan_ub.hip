@@ -1,0 +1,66 @@
+// Diagnostic micro-benchmark: k_scan8 / k_scan on random fp16 data with tau = +inf (no appends).
+//   scan_ub <rows> <dim> <B> <reps>      env HX_SCAN_DBG selects the ablation variant of k_scan8
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <cmath>
+#include "../../rag_application_amd/csrc/hx_common.hpp"
+#include "../../rag_application_amd/csrc/kernels.hpp"
+namespace hx { void set_last_error(const std::string&) {} }
+using namespace hx;
+
+__global__ void k_fill(_Float16* p, int64_t n, uint32_t seed) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (_Float16)(synth_value(seed, (uint32_t)(i >> 10), (uint32_t)(i & 1023)) * 0.05f);
+}
+__global__ void k_fillf(float* p, int n, float v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+int main(int argc, char** argv) {
+  int64_t rows = argc > 1 ? atoll(argv[1]) : 4000000;
+  int dim = argc > 2 ? atoi(argv[2]) : 768;
+  int B = argc > 3 ? atoi(argv[3]) : 1024;
+  int reps = argc > 4 ? atoi(argv[4]) : 5;
+  int old = argc > 5 ? atoi(argv[5]) : 0;
+  float tauv = argc > 6 ? (float)atof(argv[6]) : INFINITY;
+  int64_t rb = dim * 2;
+  int64_t cap = (rows + 255) / 256 * 256;
+  _Float16 *A, *Q;
+  float* tau;
+  uint64_t* cand;
+  int *cnt, *ovf;
+  int Bpad = (B + 255) / 256 * 256;
+  hipMalloc(&A, cap * rb);
+  hipMalloc(&Q, (int64_t)Bpad * rb);
+  hipMalloc(&tau, Bpad * 4);
+  hipMalloc(&cand, (int64_t)B * 2048 * 8);
+  hipMalloc(&cnt, B * 4);
+  hipMalloc(&ovf, B * 4);
+  hipMemset(cnt, 0, B * 4);
+  k_fill<<<2048, 256>>>(A, cap * dim, 1);
+  k_fill<<<256, 256>>>(Q, (int64_t)Bpad * dim, 2);
+  k_fillf<<<(Bpad + 255) / 256, 256>>>(tau, Bpad, tauv);
+  ScanArgs a{};
+  a.A = (const uint8_t*)A; a.Q = (const uint8_t*)Q; a.row_bytes = rb; a.row_begin = 0; a.row_end = rows; a.B = B;
+  a.nq_tiles = Bpad / 256; a.tau = tau; a.cand = cand; a.cnt = cnt; a.overflow = ovf; a.cap = 2048; a.id_base = 0;
+  hipMalloc(&a.hitlog, (size_t)SCAN8_WAVES * SCAN8_LOGCAP * 16); hipMalloc(&a.hitcnt, SCAN8_WAVES * 4); a.logcap = SCAN8_LOGCAP;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 2; ++w) { if (old) launch_scan(a, KIND_F16, 128, 0); else launch_scan8(a, KIND_F16, 0); }
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) { if (old) launch_scan(a, KIND_F16, 128, 0); else launch_scan8(a, KIND_F16, 0); }
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+  std::vector<int> hc(B); hipMemcpy(hc.data(), cnt, B * 4, hipMemcpyDeviceToHost);
+  double hits = 0; for (int b = 0; b < B; ++b) hits += hc[b];
+  printf("tau %g: hits/query/launch %.1f\n", tauv, hits / B / (reps + 2));
+  double fl = 2.0 * B * (double)rows * dim;
+  printf("rows %lld dim %d B %d dbg %s old %d: %.3f ms  %.1f TFLOP/s  (%s)\n", (long long)rows, dim, B,
+         getenv("HX_SCAN_DBG") ? getenv("HX_SCAN_DBG") : "0", old, ms, fl / ms / 1e9, hipGetErrorString(hipGetLastError()));
+  return 0;
+}
