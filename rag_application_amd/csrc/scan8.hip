@@ -53,11 +53,20 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+#ifndef HX_S8_TS
+#define HX_S8_TS 16
+#endif
 constexpr int S8_HT = 16384;       // half-tile bytes
 constexpr int S8_MAXQ = 4096;      // queries whose thresholds fit the LDS table
 
-template <int KIND, int DBG>
+// TS = MFMA tile side: 32 (v_mfma_*_32x32x16_f16 / 32x32x32_i8) or 16 (16x16x32_f16 / 16x16x64_i8).
+// Same LDS image, same number of 16-byte fragment reads and of matrix-pipe cycles per phase.
+template <int KIND, int TS, int DBG>
 __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
+  constexpr int MT = 64 / TS;          // row tiles of a quadrant
+  constexpr int NT = 32 / TS;          // query tiles of a quadrant
+  constexpr int KS = TS == 32 ? 4 : 2; // MFMA k-steps of a k-tile
+  constexpr int EPT = TS * TS / 64;    // accumulator registers of one tile
   constexpr int AUX = (KIND == KIND_I8 ? 2 : 1) * S8_MAXQ * 4;
   __shared__ __attribute__((aligned(1024))) uint8_t lds[8 * S8_HT + AUX];
   float* lds_tau = (float*)(lds + 8 * S8_HT);
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int r = lane & 31, hh = lane >> 5;
+  const int r = lane & (TS - 1), hh = lane / TS;   // row/column inside a tile, k-group
 
   typedef __attribute__((address_space(1))) const float GF;
   typedef __attribute__((address_space(1))) const f32x4 GF4;
@@ -116,14 +125,14 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
       offB[h][c] = (uint32_t)((rr >> 5) * 64 + h * 32 + (rr & 31)) * (uint32_t)a.row_bytes + sl;
     }
   }
-  // fragment read offsets inside a half-tile: row*128 + ((kk*2 + hh) ^ swz)*16
+  // fragment read offsets inside a half-tile: row*128 + ((ks*(8/KS) + hh) ^ swz)*16
   const int swz = (r >> 1) & 7;
-  uint32_t rdA[4], rdB[4];
+  uint32_t rdA[KS], rdB[KS];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const uint32_t s = (uint32_t)((((kk << 1) | hh) ^ swz) << 4);
-    rdA[kk] = (uint32_t)(wm * 64 + r) * 128 + s;     // + mt*4096
-    rdB[kk] = (uint32_t)(wn * 32 + r) * 128 + s;
+  for (int ks = 0; ks < KS; ++ks) {
+    const uint32_t s = (uint32_t)(((ks * (8 / KS) + hh) ^ swz) << 4);
+    rdA[ks] = (uint32_t)(wm * 64 + r) * 128 + s;     // + mt*TS*128
+    rdB[ks] = (uint32_t)(wn * 32 + r) * 128 + s;     // + nt*TS*128
   }
 
   // ---- load cursors: k-tile T+1 (c1) and T+2 (c2) -----------------------------------
@@ -150,31 +159,37 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     }
   };
   bool in_loop = false;
-  auto stage = [&](const uint8_t* base, int koff, const uint32_t (&off)[2], int slot) __attribute__((always_inline)) {
+  auto stage1 = [&](const uint8_t* base, int koff, const uint32_t (&off)[2], int slot, int c) __attribute__((always_inline)) {
     if (DBG == 2 && in_loop) return;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(base + koff + off[c]),
-                                       LDS_PTR(lds + slot * S8_HT + (wave + 8 * c) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(base + koff + off[c]),
+                                     LDS_PTR(lds + slot * S8_HT + (wave + 8 * c) * 1024), 16, 0, 0);
+  };
+  auto stage = [&](const uint8_t* base, int koff, const uint32_t (&off)[2], int slot) __attribute__((always_inline)) {
+    stage1(base, koff, off, slot, 0);
+    stage1(base, koff, off, slot, 1);
   };
 
   using frag_t = half8;
-  using acc_t = typename std::conditional<KIND == KIND_F16, f32x16, i32x16>::type;
-  acc_t acc[2][2][2];   // [ha][hb][mt]
-  frag_t af[2][4];      // current A half: [mt][kk]
-  frag_t bA[4], bB[4];  // query fragments: B0 / B1 alternate between the two sets
+  using acc_t = typename std::conditional<
+      KIND == KIND_F16, typename std::conditional<TS == 32, f32x16, f32x4>::type,
+      typename std::conditional<TS == 32, i32x16, i32x4>::type>::type;
+  acc_t acc[2][2][MT][NT];   // [ha][hb][mt][nt]
+  frag_t af[MT][KS];         // current A half
+  frag_t bA[NT][KS], bB[NT][KS];  // query fragments: B0 / B1 alternate between the two sets
 
   auto read_a = [&](int slot) __attribute__((always_inline)) {
     const uint8_t* s = lds + slot * S8_HT;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) af[mt][kk] = *(const frag_t*)(s + rdA[kk] + mt * 4096);
+      for (int ks = 0; ks < KS; ++ks) af[mt][ks] = *(const frag_t*)(s + rdA[ks] + mt * (TS * 128));
   };
-  auto read_b = [&](int slot, frag_t (&b)[4]) __attribute__((always_inline)) {
+  auto read_b = [&](int slot, frag_t (&b)[NT][KS]) __attribute__((always_inline)) {
     const uint8_t* s = lds + slot * S8_HT;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) b[kk] = *(const frag_t*)(s + rdB[kk]);
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) b[nt][ks] = *(const frag_t*)(s + rdB[ks] + nt * (TS * 128));
   };
 
   // ---- prologue: half-tiles g = 0..5 ---------------------------------------------------
@@ -203,106 +218,153 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   auto* g_log = (__attribute__((address_space(1))) u32x4*)a.hitlog +
                 (int64_t)(blockIdx.x * 8 + wave) * a.logcap;
   int wpos = 0;   // entries this wave has logged (scalar)
-  auto filter = [&](int rt, int qt, int ha, int hb, acc_t (&c)[2]) __attribute__((always_inline)) {
-    const int q = qt * 256 + wn * 64 + hb * 32 + r;
-    const float tau = lds_tau[q];
+  auto filter = [&](int rt, int qt, int ha, int hb, acc_t (&c)[MT][NT]) __attribute__((always_inline)) {
+    // lane owns query column r of each of the NT tiles and, per row tile, EPT rows:
+    //   TS = 32: rows 8*(e>>2) + 4*hh + (e&3);  TS = 16: rows 4*hh + e   (4 consecutive per group)
+    const int q0 = qt * 256 + wn * 64 + hb * 32 + r;
     const int64_t rowq = a.row_begin + (int64_t)rt * 256 + wm * 128 + ha * 64 + 4 * hh;
-    float sc[2][16];
-    if constexpr (KIND == KIND_F16) {
+    auto max3 = [](float x, float y, float z) __attribute__((always_inline)) {
+      float o;
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z));
+      return o;
+    };
+    constexpr int NG = EPT / 4;   // groups of 4 consecutive rows per tile
+    float tau[NT], sc[NT][MT][EPT], gm[NT][MT][NG], m[NT];
+    bool any = false;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+      tau[nt] = lds_tau[q0 + nt * TS];
+      float rq = 0.f;
+      if constexpr (KIND == KIND_I8) rq = lds_rq[q0 + nt * TS];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sc[mt][e] = c[mt][e];
-    } else {
-      const float rq = lds_rq[q];
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int g = 0; g < NG; ++g) {
+          if constexpr (KIND == KIND_F16) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 rx = *(const GF4*)(g_rinv_x + rowq + mt * 32 + 8 * g);   // padded past n_rows
-          sc[mt][4 * g + 0] = ((float)c[mt][4 * g + 0] * rx.x) * rq;
-          sc[mt][4 * g + 1] = ((float)c[mt][4 * g + 1] * rx.y) * rq;
-          sc[mt][4 * g + 2] = ((float)c[mt][4 * g + 2] * rx.z) * rq;
-          sc[mt][4 * g + 3] = ((float)c[mt][4 * g + 3] * rx.w) * rq;
-        }
-    }
-    // maxima of the 8 groups of 4 consecutive rows, then of the quadrant: the common case (no
-    // lane reaches its threshold) leaves after ~20 VALU instructions
-    float gm[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        gm[mt][g] = __builtin_fmaxf(__builtin_fmaxf(sc[mt][4 * g], sc[mt][4 * g + 1]),
-                                    __builtin_fmaxf(sc[mt][4 * g + 2], sc[mt][4 * g + 3]));
-    const float m = __builtin_fmaxf(
-        __builtin_fmaxf(__builtin_fmaxf(gm[0][0], gm[0][1]), __builtin_fmaxf(gm[0][2], gm[0][3])),
-        __builtin_fmaxf(__builtin_fmaxf(gm[1][0], gm[1][1]), __builtin_fmaxf(gm[1][2], gm[1][3])));
-    if (__builtin_amdgcn_ballot_w64(m >= tau) == 0ull) return;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (__builtin_amdgcn_ballot_w64(gm[mt][g] >= tau) == 0ull) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t row = rowq + mt * 32 + 8 * g + i;
-          const float s = sc[mt][4 * g + i];
-          const bool hit = s >= tau && row < a.row_end;
-          const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
-          if (mask == 0ull) continue;
-          const int idx = wpos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-          if (hit) {
-            if (idx < a.logcap) {
-              const uint64_t key = make_key(s, (uint32_t)(a.id_base + row));
-              g_log[idx] = u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)q, 0u};
-            } else {
-              g_ovf[q] = 1;
-            }
+            for (int i = 0; i < 4; ++i) sc[nt][mt][4 * g + i] = c[mt][nt][4 * g + i];
+          } else {
+            const f32x4 rx = *(const GF4*)(g_rinv_x + rowq + mt * TS + 8 * g);   // padded past n_rows
+            sc[nt][mt][4 * g + 0] = ((float)c[mt][nt][4 * g + 0] * rx.x) * rq;
+            sc[nt][mt][4 * g + 1] = ((float)c[mt][nt][4 * g + 1] * rx.y) * rq;
+            sc[nt][mt][4 * g + 2] = ((float)c[mt][nt][4 * g + 2] * rx.z) * rq;
+            sc[nt][mt][4 * g + 3] = ((float)c[mt][nt][4 * g + 3] * rx.w) * rq;
           }
-          wpos += __builtin_popcountll(mask);
+          // (v_max3_f32 returns the maximum of the non-NaN operands; garbage rows past the end
+          // of the matrix may hold NaNs and are dropped by the row < row_end test anyway)
+          gm[nt][mt][g] = max3(max3(sc[nt][mt][4 * g], sc[nt][mt][4 * g + 1], sc[nt][mt][4 * g + 2]),
+                               sc[nt][mt][4 * g + 3], sc[nt][mt][4 * g + 3]);
         }
-      }
+      float mm = gm[nt][0][0];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) mm = max3(mm, gm[nt][mt][g], gm[nt][mt][g]);
+      m[nt] = mm;
+      any |= (mm >= tau[nt]);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) == 0ull, 1)) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (__builtin_amdgcn_ballot_w64(gm[nt][mt][g] >= tau[nt]) == 0ull) continue;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int64_t row = rowq + mt * TS + 8 * g + i;
+            const float s = sc[nt][mt][4 * g + i];
+            const bool hit = s >= tau[nt] && row < a.row_end;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
+            if (mask == 0ull) continue;
+            const int idx = wpos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (hit) {
+              const int q = q0 + nt * TS;
+              if (idx < a.logcap) {
+                const uint64_t key = make_key(s, (uint32_t)(a.id_base + row));
+                g_log[idx] = u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)q, 0u};
+              } else {
+                g_ovf[q] = 1;
+              }
+            }
+            wpos += __builtin_popcountll(mask);
+          }
+        }
   };
 
-  auto mma = [&](acc_t (&c)[2], const frag_t (&b)[4], bool first) __attribute__((always_inline)) {
+  // MFMAs of k-steps [ks0, ks1) of one quadrant
+  auto mma = [&](acc_t (&c)[MT][NT], const frag_t (&b)[NT][KS], bool first, int ks0, int ks1) __attribute__((always_inline)) {
     if constexpr (DBG == 3) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        asm volatile("" ::"v"(b[kk]));
+      for (int ks = ks0; ks < ks1; ++ks) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) asm volatile("" ::"v"(af[mt][kk]));
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(b[nt][ks]));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(af[mt][ks]));
       }
-      if (first) { c[0] = acc_t{}; c[1] = acc_t{}; }
+      if (first && ks0 == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) c[mt][nt] = acc_t{};
+      }
       return;
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int ks = ks0; ks < ks1; ++ks)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        if constexpr (KIND == KIND_F16) {
-          const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          c[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][kk], b[kk], (first && kk == 0) ? z : c[mt], 0, 0, 0);
-        } else {
-          const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          c[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, af[mt][kk]),
-                                                        __builtin_bit_cast(i32x4, b[kk]),
-                                                        (first && kk == 0) ? z : c[mt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const acc_t z = acc_t{};
+          const acc_t cin = (first && ks == 0) ? z : c[mt][nt];
+          if constexpr (KIND == KIND_F16 && TS == 32)
+            c[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][ks], b[nt][ks], cin, 0, 0, 0);
+          else if constexpr (KIND == KIND_F16 && TS == 16)
+            c[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][ks], b[nt][ks], cin, 0, 0, 0);
+          else if constexpr (TS == 32)
+            c[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, af[mt][ks]),
+                                                              __builtin_bit_cast(i32x4, b[nt][ks]), cin, 0, 0, 0);
+          else
+            c[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[mt][ks]),
+                                                              __builtin_bit_cast(i32x4, b[nt][ks]), cin, 0, 0, 0);
         }
-      }
   };
 
-#define S8_L_END()                                   \
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   \
-  __builtin_amdgcn_sched_barrier(0);                 \
-  __builtin_amdgcn_s_barrier();                      \
-  __builtin_amdgcn_sched_barrier(0);                 \
-  __builtin_amdgcn_s_setprio(1);
-#define S8_M_END()                                   \
-  __builtin_amdgcn_s_setprio(0);                     \
-  __builtin_amdgcn_sched_barrier(0);                 \
-  __builtin_amdgcn_s_barrier();                      \
+#ifndef HX_S8_SPLIT
+#define HX_S8_SPLIT 2
+#endif
+  // Where the two loads of a phase are issued: 0 = both in the L segment (vmcnt 6), 1 = one in L
+  // and one between the MFMAs (vmcnt 5), 2 = both between the MFMAs (vmcnt 4).
+#define S8_WAIT() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 - HX_S8_SPLIT) : "memory")
+#define S8_PHASE(READS, BASE, KOFF, OFF, SLOT, ACC, BF, HA, HB)                 \
+  READS;                                                                        \
+  if (HX_S8_SPLIT <= 1) stage1(BASE, KOFF, OFF, SLOT, 0);                       \
+  if (HX_S8_SPLIT == 0) stage1(BASE, KOFF, OFF, SLOT, 1);                       \
+  S8_WAIT();                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  __builtin_amdgcn_s_barrier();                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  __builtin_amdgcn_s_setprio(1);                                                \
+  mma(ACC, BF, FIRST, 0, 1);                                                    \
+  if (HX_S8_SPLIT >= 1) {                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    stage1(BASE, KOFF, OFF, SLOT, HX_S8_SPLIT == 1 ? 1 : 0);                    \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+  }                                                                             \
+  mma(ACC, BF, FIRST, 1, KS == 4 ? 3 : 2);                                      \
+  if (HX_S8_SPLIT == 2) {                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    stage1(BASE, KOFF, OFF, SLOT, 1);                                           \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+  }                                                                             \
+  mma(ACC, BF, FIRST, KS == 4 ? 3 : 2, KS);                                     \
+  if (__builtin_expect(last, 0)) filter(rt, qt, HA, HB, ACC);                   \
+  __builtin_amdgcn_s_setprio(0);                                                \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  __builtin_amdgcn_s_barrier();                                                 \
   __builtin_amdgcn_sched_barrier(0);
 
   // one k-tile = four phases.  PAR = T & 1 (ring half and the B register set holding B0).
@@ -310,8 +372,8 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr bool FIRST = decltype(first_c)::value;
     constexpr int S0 = 4 * PAR, N0 = 4 * (1 - PAR);
-    frag_t(&b0)[4] = PAR ? bB : bA;
-    frag_t(&b1)[4] = PAR ? bA : bB;
+    frag_t(&b0)[NT][KS] = PAR ? bB : bA;
+    frag_t(&b1)[NT][KS] = PAR ? bA : bB;
     const bool last = (c_kt == KT - 1);
     int rt = 0, qt = 0;
     if (last) {
@@ -320,34 +382,11 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
       qt = cj - d * nq;
     }
 
-    // phase 0: C00 += A0 . B0
-    read_a(S0 + 0);
-    stage(c1.q, c1.koff, offB[1], N0 + 2);
-    S8_L_END();
-    mma(acc[0][0], b0, FIRST);
-    if (last) filter(rt, qt, 0, 0, acc[0][0]);
-    S8_M_END();
-    // phase 1: C01 += A0 . B1
-    read_b(S0 + 2, b1);
-    stage(c1.a, c1.koff, offA[1], N0 + 3);
-    S8_L_END();
-    mma(acc[0][1], b1, FIRST);
-    if (last) filter(rt, qt, 0, 1, acc[0][1]);
-    S8_M_END();
-    // phase 2: C11 += A1 . B1
-    read_a(S0 + 3);
-    stage(c2.a, c2.koff, offA[0], S0 + 0);
-    S8_L_END();
-    mma(acc[1][1], b1, FIRST);
-    if (last) filter(rt, qt, 1, 1, acc[1][1]);
-    S8_M_END();
-    // phase 3: C10 += A1 . B0 ; B0 of the next k-tile replaces B1
-    read_b(N0 + 1, b1);
-    stage(c2.q, c2.koff, offB[0], S0 + 1);
-    S8_L_END();
-    mma(acc[1][0], b0, FIRST);
-    if (last) filter(rt, qt, 1, 0, acc[1][0]);
-    S8_M_END();
+    // C00 += A0.B0 | C01 += A0.B1 | C11 += A1.B1 | C10 += A1.B0 (B0 of the next k-tile replaces B1)
+    S8_PHASE(read_a(S0 + 0), c1.q, c1.koff, offB[1], N0 + 2, acc[0][0], b0, 0, 0)
+    S8_PHASE(read_b(S0 + 2, b1), c1.a, c1.koff, offA[1], N0 + 3, acc[0][1], b1, 0, 1)
+    S8_PHASE(read_a(S0 + 3), c2.a, c2.koff, offA[0], S0 + 0, acc[1][1], b1, 1, 1)
+    S8_PHASE(read_b(N0 + 1, b1), c2.q, c2.koff, offB[0], S0 + 1, acc[1][0], b0, 1, 0)
 
     c1 = c2;
     advance(c2);
@@ -371,8 +410,8 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the never-read tail loads
   if (wm == 0) __builtin_amdgcn_s_barrier();
   if (lane == 0) a.hitcnt[blockIdx.x * 8 + wave] = wpos;
-#undef S8_L_END
-#undef S8_M_END
+#undef S8_PHASE
+#undef S8_WAIT
 }
 
 // one workgroup per wave log: entries -> the per-query candidate buffers (order is irrelevant,
@@ -410,15 +449,15 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st) {
   g = (g + 7) / 8 * 8;
 #ifdef HX_SCAN_DBG
   static const int dbg = getenv("HX_SCAN_DBG") ? atoi(getenv("HX_SCAN_DBG")) : 0;
-  if (kind == KIND_F16 && dbg == 1) hipLaunchKernelGGL((k_scan8<KIND_F16, 1>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_F16 && dbg == 2) hipLaunchKernelGGL((k_scan8<KIND_F16, 2>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_F16 && dbg == 3) hipLaunchKernelGGL((k_scan8<KIND_F16, 3>), dim3((unsigned)g), dim3(512), 0, st, a);
+  if (kind == KIND_F16 && dbg == 1) hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 1>), dim3((unsigned)g), dim3(512), 0, st, a);
+  else if (kind == KIND_F16 && dbg == 2) hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 2>), dim3((unsigned)g), dim3(512), 0, st, a);
+  else if (kind == KIND_F16 && dbg == 3) hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 3>), dim3((unsigned)g), dim3(512), 0, st, a);
   else
 #endif
   if (kind == KIND_F16)
-    hipLaunchKernelGGL((k_scan8<KIND_F16, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
   else
-    hipLaunchKernelGGL((k_scan8<KIND_I8, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
   HX_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_scatter_log, dim3((unsigned)g * 8), dim3(256), 0, st, a.hitlog, a.hitcnt, a.logcap, a.cand,
                      a.cnt, a.overflow, a.cap);
