@@ -12,6 +12,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <tuple>
+#include <cmath>
 #include <numeric>
 #include <vector>
 
@@ -46,7 +48,7 @@ enum WsSlot {
   WS_NFAIL, WS_QSEL, WS_FB_KEYS, WS_FB_CNT, WS_FB_INCNT, WS_SP_PARTS, WS_SP_PCNT, WS_RAW, WS_RS_TMP,
   WS_T_A, WS_T_ACNT, WS_T_B, WS_T_BCNT, WS_T_C, WS_T_CCNT, WS_T_D, WS_T_DCNT, WS_T_E, WS_T_ECNT,
   WS_T_F, WS_T_FCNT, WS_T_G, WS_T_GCNT, WS_H_QD, WS_H_QIP, WS_H_QIX, WS_H_QV, WS_H_OUT, WS_H_OCNT,
-  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT
+  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT, WS_KEPT
 };
 
 template <typename T>
@@ -186,24 +188,70 @@ struct Geometry {
   int Lp;     // candidates kept by the approximate pass
   int C;      // per-query buffer capacity (power of two <= CAND_CAP)
   int grow;   // chunk growth factor
+  bool predictive;
 };
-// A chunk scanned with the threshold tau = Lp-th best of the n0 rows before it
-// appends about (grow-1)*Lp keys per query when it spans [n0, grow*n0); the pass rate
-// of that order statistic has relative standard deviation 1/sqrt(Lp).  grow is chosen
-// so that the mean plus five such deviations still fits the buffer; an overflow is
-// detected (never silent) and the query is retried with `safe` geometry.
+// Threshold of a chunk.  Rows are scanned in geometrically growing chunks [n0, g*n0); a chunk
+// appends every row whose score reaches tau and the buffer is then compacted to the best Lp.
+//   classic    tau = Lp-th best so far: about (g-1)*Lp appended per query, always exact;
+//   predictive tau = kq-th best so far, kq < Lp: the Lp-th best of g*n0 rows sits near the
+//              (Lp/g)-th best of the first n0, so about kq*(g-1) are appended -- several times
+//              fewer.  The kept list is still the exact top-Lp provided at least Lp rows reach
+//              tau, i.e. kq + appended >= Lp; k_compact checks exactly that and flags the query
+//              otherwise (it is then retried with the classic rule, as after an overflow).
+// The count appended given tau is Poisson with mean (g-1)*G, G ~ Gamma(kq): a negative binomial
+// NB(kq, 1/g).  kq is the smallest rank with P(appended < Lp - kq) <= 1e-7, and g the largest
+// growth (<= 64) with P(appended > C - Lp) <= 1e-7 -- both from the exact distribution.
+constexpr double PREDICT_EPS = 1e-7;
+// P(X <= kmax), X ~ NB(r, p): failures before the r-th success
+static double nb_cdf(int r, double p, int kmax) {
+  if (kmax < 0) return 0.0;
+  if (p >= 1.0) return 1.0;
+  const double lq = std::log1p(-p);
+  double lp = r * std::log(p), sum = 0.0;   // log pmf(0)
+  for (int k = 0; k <= kmax; ++k) {
+    sum += std::exp(lp);
+    lp += std::log((double)(k + r) / (double)(k + 1)) + lq;
+  }
+  return sum;
+}
+static int predict_rank(int Lp, double g_eff) {
+  if (g_eff <= 1.0) return Lp;
+  static thread_local std::map<std::pair<int, int64_t>, int> cache;
+  const auto key = std::make_pair(Lp, (int64_t)(g_eff * 1024.0));
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int lo = std::min(8, Lp), hi = Lp;   // smallest kq in [lo, Lp) whose underflow tail is small enough
+  while (lo < hi) {
+    const int kq = (lo + hi) / 2;
+    if (nb_cdf(kq, 1.0 / g_eff, Lp - kq - 1) <= PREDICT_EPS) hi = kq;
+    else lo = kq + 1;
+  }
+  return cache[key] = lo;
+}
 static Geometry geometry(int L, bool approx, bool safe) {
+  static thread_local std::map<std::tuple<int, bool, bool>, Geometry> cache;
+  const auto key = std::make_tuple(L, approx, safe);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
   Geometry g;
   g.Lp = approx ? L + std::max(32, L / 2) : L;
   if (safe) g.Lp = std::min(std::max(2 * g.Lp, g.Lp + 256), CAND_CAP / 4);
   int c = next_pow2(std::max(8 * g.Lp, 1024));
   g.C = safe ? CAND_CAP : std::min(c, CAND_CAP);
   HX_CHECK(g.Lp * 2 <= g.C && g.Lp >= L, "limit too large");
-  const double per = g.Lp * (1.0 + 5.0 / std::sqrt((double)g.Lp));
-  g.grow = 1 + (int)((g.C - g.Lp) / per);
-  if (safe) g.grow = 2;
-  if (g.grow < 2) g.grow = 2;
-  return g;
+  g.predictive = false;
+  g.grow = 2;
+  if (!safe) {
+    for (int gr = 64; gr > 2; --gr) {
+      const int kq = predict_rank(g.Lp, (double)gr);
+      if (kq < g.Lp && 1.0 - nb_cdf(kq, 1.0 / gr, g.C - g.Lp) <= PREDICT_EPS) {
+        g.grow = gr;
+        g.predictive = true;
+        break;
+      }
+    }
+  }
+  return cache[key] = g;
 }
 
 // query-tile width of the scan kernel for a batch of B queries
@@ -284,7 +332,10 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   }
   a.hitcnt = hitcnt;
   a.logcap = SCAN8_LOGCAP;
+  int* kept = (int*)h->ws.get(WS_KEPT, (size_t)B * 4);
+  HX_HIP(hipMemsetAsync(kept, 0, (size_t)B * 4, st));
   int64_t r0 = 0, r1 = std::min<int64_t>(h->n, g.C);
+  int chk_rank = 0;   // rank whose score is the threshold of the chunk being scanned (0: none)
   while (r0 < h->n) {
     a.row_begin = r0;
     a.row_end = r1;
@@ -295,11 +346,13 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
       ProfScope ps(h, st, kind, 2.0 * B * rows * elems, rows * (double)row_bytes + (double)B * row_bytes);
       launch_scan(a, kind, bn, st);
     }
-    launch_compact(cand, g.C, cnt, B, g.Lp, 0, cand, g.C, cnt, tau, g.C, st);
-    r0 = r1;
     // rows per launch bounded so the kernel's 32-bit tile counters cannot wrap
-    const int64_t next = std::min<int64_t>(r1 * g.grow, r1 + (1ll << 27));
-    r1 = std::min<int64_t>(h->n, next);
+    const int64_t next = std::min<int64_t>(h->n, std::min<int64_t>(r1 * g.grow, r1 + (1ll << 27)));
+    const int next_rank = (g.predictive && next > r1) ? predict_rank(g.Lp, (double)next / (double)r1) : g.Lp;
+    launch_compact(cand, g.C, cnt, B, g.Lp, 0, cand, g.C, cnt, tau, g.C, st, next_rank, chk_rank, kept, ovf);
+    chk_rank = next_rank < g.Lp ? next_rank : 0;
+    r0 = r1;
+    r1 = next;
   }
 }
 

@@ -48,9 +48,13 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st);   // includes th
 // duplicate keys, keep `keep`; writes out_keys[b*out_stride + r] (may alias `keys`
 // when out_stride == stride), out_cnt[b], and tau[b] = score of the keep-th key when
 // the list is full, else -inf (tau may be NULL).  in_cnt NULL => all `stride` slots.
+// tau_rank (1-based, default keep): rank whose score becomes tau.  kept_io (optional): per-list
+// count kept by the previous compaction of the same buffer, updated; with chk_rank > 0 the
+// list is flagged in `underflow` when chk_rank + (keys appended since) < keep.
 void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int keep, int dedupe,
                     uint64_t* out_keys, int out_stride, int* out_cnt, float* tau,
-                    int max_cnt_hint, hipStream_t st);
+                    int max_cnt_hint, hipStream_t st, int tau_rank = 0, int chk_rank = 0,
+                    int* kept_io = nullptr, int* underflow = nullptr);
 
 // Exact spec score of listed candidates: out_keys[b*stride + i] = key(spec_dot(row, q_b), id)
 // for i < min(cnt[b], stride); ids outside [id_base, id_base+n) give key 0.

@@ -12,13 +12,15 @@ namespace hx {
 __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ keys, int stride,
                                                  const int* __restrict__ in_cnt, int P, int keep,
                                                  int dedupe, uint64_t* out_keys, int out_stride,
-                                                 int* out_cnt, float* tau) {
+                                                 int* out_cnt, float* tau, int tau_rank, int chk_rank,
+                                                 int* kept_io, int* underflow) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint64_t* sk = (uint64_t*)smem;
   __shared__ int part[256];
   __shared__ uint64_t s_kth;
   const int b = blockIdx.x, tid = threadIdx.x;
   int n = in_cnt ? in_cnt[b] : stride;
+  const int n_raw = n;
   n = n < stride ? n : stride;
   n = n < P ? n : P;
   for (int i = tid; i < P; i += 256) sk[i] = i < n ? keys[(int64_t)b * stride + i] : 0ull;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ ke
     const bool f = x != 0ull && (!dedupe || i == 0 || x != sk[i - 1]);
     if (f) {
       if (pos < keep) o[pos] = x;
-      if (pos == keep - 1) s_kth = x;
+      if (pos == tau_rank - 1) s_kth = x;
       ++pos;
     }
   }
@@ -79,12 +81,20 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ ke
   if (tid == 0) {
     out_cnt[b] = kept;
     if (tau) tau[b] = (total >= keep && keep > 0) ? key_score(s_kth) : -__builtin_inff();
+    if (kept_io) {
+      // The keys appended since the previous compaction passed the score of its rank chk_rank.  The
+      // kept list is the exact top-`keep` only if at least `keep` rows reach that score: chk_rank of
+      // the old list do, plus every appended one (engine.hip, chunked_scan).
+      const int prev = kept_io[b];
+      if (chk_rank > 0 && prev >= keep && chk_rank + (n_raw - prev) < keep) underflow[b] = 1;
+      kept_io[b] = kept;
+    }
   }
 }
 
 void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int keep, int dedupe,
                     uint64_t* out_keys, int out_stride, int* out_cnt, float* tau, int max_cnt_hint,
-                    hipStream_t st) {
+                    hipStream_t st, int tau_rank, int chk_rank, int* kept_io, int* underflow) {
   if (B <= 0) return;
   int m = max_cnt_hint < stride ? max_cnt_hint : stride;
   int P = next_pow2(m < 256 ? 256 : m);
@@ -96,8 +106,10 @@ void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int ke
                                CAND_CAP * 8));
     attr_set = true;
   }
+  if (tau_rank <= 0 || tau_rank > keep) tau_rank = keep;
+  HX_CHECK(!kept_io || underflow, "compact: kept_io without an underflow flag array");
   hipLaunchKernelGGL(k_compact, dim3(B), dim3(256), (size_t)P * 8, st, keys, stride, in_cnt, P, keep,
-                     dedupe, out_keys, out_stride, out_cnt, tau);
+                     dedupe, out_keys, out_stride, out_cnt, tau, tau_rank, chk_rank, kept_io, underflow);
   HX_HIP(hipGetLastError());
 }
 
