@@ -43,8 +43,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override corpus rows (testing)")
     ap.add_argument("--batch", type=int, default=0, help="override query batch (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-queries", type=int, default=128)
+    ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--cpu-queries", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (box share per GPU)")
     return ap.parse_args()
 
@@ -171,10 +171,22 @@ def main():
         tf = sc["flops"] / sec / 1e12
         gbs = sc["bytes"] / sec / 1e9
         mfma_bound = (sc["flops"] / (PEAK_FP16_TFLOPS * 1e12)) >= (sc["bytes"] / (PEAK_HBM_GBS * 1e9))
-        roof = dict(kernel="k_scan<fp16,32x32x16 MFMA>", bound="mfma" if mfma_bound else "hbm",
+        # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE pass of this same command (gfx950
+        # correction x2, MI355X_MICROARCH.md), kept under profiles/ -- counters cannot be read from
+        # inside the timed process.  null when no pass for this configuration is committed.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_scan_v3.json")
+        if world == 1 and os.path.exists(tpath):
+            with open(tpath) as f:
+                tp = json.load(f)
+            if tp.get("config") == {"rows": rows, "dim": dim, "batch": B, "n_gpus": 1}:
+                traffic = tp["scan_traffic_gb_per_step"] / max(sc["launches"] / args.steps, 1)
+        roof = dict(kernel="k_scan8<fp16, v_mfma_f32_16x16x32_f16> (256x256 tile; first chunk: k_scan)",
+                    bound="mfma" if mfma_bound else "hbm",
                     achieved=tf if mfma_bound else gbs, peak=PEAK_FP16_TFLOPS if mfma_bound else PEAK_HBM_GBS,
                     unit="TFLOP/s" if mfma_bound else "GB/s",
-                    frac=(tf / PEAK_FP16_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS), traffic=None,
+                    frac=(tf / PEAK_FP16_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS), traffic=traffic,
+                    traffic_unit="GB per launch (profiles/r01_pmc_scan_v3.json)",
                     launches=sc["launches"], avg_launch_ms=sc["ms"] / sc["launches"],
                     alg_tflop_per_launch=sc["flops"] / sc["launches"] / 1e12,
                     alg_gb_per_launch=sc["bytes"] / sc["launches"] / 1e9,
