@@ -154,9 +154,9 @@ static void prep_rows_device(hx_index* h, const float* raw_dev, int64_t n, hipSt
 }
 
 static void free_sparse_index(hx_index* h) {
-  if (h->sp.doc_local) (void)hipFree(h->sp.doc_local);
-  if (h->sp.w) (void)hipFree(h->sp.w);
-  if (h->sp.table) (void)hipFree(h->sp.table);
+  if (h->sp.post) (void)hipFree(h->sp.post);
+  if (h->sp.ptr) (void)hipFree(h->sp.ptr);
+  if (h->sp.uterms) (void)hipFree(h->sp.uterms);
   h->sp = SparseBuildOut{};
   h->n_segments = 0;
   h->sp_docs_built = 0;
@@ -553,10 +553,10 @@ static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q
   uint64_t* pk = (uint64_t*)h->ws.get(WS_SP_PARTS, (size_t)B * parts * L * 8);
   int* pc = (int*)h->ws.get(WS_SP_PCNT, (size_t)B * parts * 4);
   SparseQueryArgs a{};
-  a.ix.doc_local = h->sp.doc_local;
-  a.ix.w = h->sp.w;
-  a.ix.table = h->sp.table;
-  a.ix.table_mask = h->sp.table_cap - 1;
+  a.ix.post = h->sp.post;
+  a.ix.ptr = h->sp.ptr;
+  a.ix.uterms = h->sp.uterms;
+  a.ix.n_live = (int)h->sp.n_live;
   a.ix.n_docs = h->sp_docs_built;
   a.ix.n_segments = h->n_segments;
   a.ix.id_base = h->id_base;
@@ -1072,8 +1072,8 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   out->n_rows = h->n;
   out->nnz = h->nnz;
   out->n_segments = h->n_segments;
-  out->n_groups = h->sp.n_groups;
-  out->hash_capacity = (int64_t)h->sp.table_cap;
+  out->n_groups = h->sp.n_live;              // live terms
+  out->hash_capacity = h->sp.ptr_entries;    // entries of the term x segment offset table
   out->bytes_dense_f32 = h->n * h->dim_pad * 4;
   out->bytes_dense_f16 = h->n * h->dim_pad * 2;
   out->bytes_i8 = h->n * h->dim_pad8;
@@ -1081,7 +1081,7 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   for (int p = 0; p < h->n_pre; ++p) bp += h->n * h->psize[p] * 4;
   if (h->n_pre) bp += h->n * h->psize[0] * 2;
   out->bytes_prefix = bp;
-  out->bytes_sparse = h->nnz * 6 + (int64_t)h->sp.table_cap * (int64_t)sizeof(SpHashEntry);
+  out->bytes_sparse = h->nnz * 8 + h->sp.ptr_entries * 4 + h->sp.n_live * 4;
   out->dense_fallback_queries = h->dense_fallbacks;
   out->i8_fallback_queries = h->i8_fallbacks;
   HX_CATCH

@@ -132,15 +132,15 @@ void launch_prep_queries_i8(const float* q_raw, int q_dim, int B, int Bpad, int 
 // ---- sparse.hip --------------------------------------------------------------
 constexpr int SEG_DOCS = 8192;        // docs per index segment (LDS accumulator: 8 B per doc = 64 KiB)
 constexpr int SP_CAND = 8192;         // per-workgroup candidate buffer (keys, global memory)
-struct SpHashEntry {
-  uint64_t key;            // (segment << 31) | term ; ~0 = empty
-  uint32_t off, len;
-};
+// Term-major inverted index: the postings of live term i (ascending document) are
+// post[ptr[i*(n_segments+1) + 0] .. ptr[i*(n_segments+1) + n_segments]); ptr[i*(S+1) + s] is
+// the first posting of term i whose document lies in segment s or later.  A posting is
+// {document index inside its segment, fp32 weight bits}.
 struct SparseIndexView {
-  const uint16_t* doc_local;   // [nnz] segment-major, term-sorted postings
-  const float* w;              // [nnz]
-  const SpHashEntry* table;
-  uint64_t table_mask;
+  const uint2* post;           // [nnz]
+  const uint32_t* ptr;         // [n_live x (n_segments + 1)]
+  const uint32_t* uterms;      // [n_live] live term ids, ascending
+  int n_live;
   int64_t n_docs;
   int n_segments;
   int64_t id_base;
@@ -164,11 +164,11 @@ void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st);
 
 // ---- spbuild.hip -------------------------------------------------------------
 struct SparseBuildOut {
-  uint16_t* doc_local;
-  float* w;
-  SpHashEntry* table;
-  uint64_t table_cap;
-  int64_t n_groups;
+  uint2* post;
+  uint32_t* ptr;
+  uint32_t* uterms;
+  int64_t n_live;
+  int64_t ptr_entries;
 };
 // Build the segment-major inverted index from doc-major CSR on the device.
 void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,

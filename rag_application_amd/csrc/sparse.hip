@@ -12,62 +12,44 @@
 // order-independently (it differs from it by at most a few fp32 ulps) and lets all
 // postings of a segment be accumulated concurrently with LDS integer atomics.
 //
-// Index layout (spbuild.hip): documents are cut into segments of SEG_DOCS; inside a
-// segment postings are sorted by (term, doc) as {u16 doc_local, f32 weight}; an
-// open-addressing table maps (segment, term) -> (offset, length).
+// Index layout (spbuild.hip): TERM-major.  Postings are sorted by (term, document) as
+// {document index inside its segment, fp32 weight}; documents are cut into segments of
+// SEG_DOCS, and a dense table gives, for every live term and segment, the offset of the
+// term's first posting in that segment or later -- the run of (term, segment) is
+// [ptr[t][s], ptr[t][s+1]) and the runs of consecutive segments are adjacent in memory.
 //
-// One 256-thread workgroup owns (query, part): a contiguous range of segments and a
-// 64 KiB LDS accumulator (one marked 64-bit word per document of the segment).  The fast
-// path (<= SP_TMAX query terms) is software-pipelined across segments with two barriers
-// per segment; wave 0 runs the directory while waves 1-3 carry the postings:
-//     accumulate(seg) from registers; wave 0 publishes the chunk table of seg+2 from
-//     the directory probes it issued a visit ago and issues the probes of seg+3
+// One 512-thread workgroup owns (query, part): a contiguous range of segments and a
+// 64 KiB LDS accumulator (one marked 64-bit word per document of the segment).  Lane t of
+// every 16-lane row holds query term t: its table row, the offsets of the current and the
+// next segment.  Per segment ("visit") every wave derives the same chunk list -- a run of
+// length len is ceil(len/64) chunks of consecutive postings -- from a DPP row scan of the
+// chunk counts, and wave w takes chunks w, w+8 (then w+16, ... for unusually long
+// segments): a chunk is wave-uniform, found with one ballot and three v_readlane.
+//     accumulate(seg) from registers (LDS integer atomics); derive the chunks of seg+1 from
+//     the offsets loaded a visit ago, issue its posting loads and the offsets of seg+3
 //                                                                     -- barrier X --
-//     issue the posting loads of seg+2; harvest(seg): one LDS exchange per posting,
-//     the thread that gets the (never zero) marked sum back owns the document
+//     harvest(seg): one LDS exchange per posting, the thread that gets the (never zero)
+//     marked sum back owns the document
 //                                                                     -- barrier Y --
-// Prefetch loads are issued from inline asm and retired by ONE counted wait per visit
-// whose operands are the registers being consumed (see sp_wait_slots): hipcc does not
-// track them, so it can neither pull a wait up to the load nor drain the queue early.
-// Survivors (score >= the running threshold) go to a per-workgroup buffer in global
-// memory that is sorted through the (then all-zero) accumulator and cut to `limit`
-// whenever it has grown by a few times `limit`.
+// Both barriers are LDS-only (no vmcnt wait), so the loads of the next visit stay in flight
+// across them.  Survivors (score >= the running threshold) go to a per-workgroup buffer in
+// global memory that is sorted through the (then all-zero) accumulator and cut to `limit`
+// whenever it has grown by a few times `limit`.  Queries with more than 16 terms take the
+// same steps per group of 16 terms without the prefetch.
+#include <type_traits>
 #include "hx_common.hpp"
 #include "kernels.hpp"
 
 namespace hx {
 
-// Diagnostic build only (-DHX_SP_STAMP): wave 0 accumulates s_memtime deltas per phase
-// into a debug buffer of its own (never read by the kernel, never in a timed build).
-#ifdef HX_SP_STAMP
-__device__ unsigned long long g_sp_stamps[8 * 4096];
-#define SP_STAMP_DECL unsigned long long st_t0 = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SP_STAMP(i) { const unsigned long long st_t1 = clock64(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; }
-#define SP_STAMP_FLUSH if (tid == 0 && blockIdx.x < 4096) for (int i_ = 0; i_ < 8; ++i_) g_sp_stamps[blockIdx.x * 8 + i_] = st_acc[i_];
-#else
-#define SP_STAMP_DECL
-#define SP_STAMP(i)
-#define SP_STAMP_FLUSH
-#endif
-
-constexpr int SP_THREADS = 256;
+constexpr int SP_THREADS = 512;
 constexpr int SP_WAVES = SP_THREADS / 64;
-constexpr int SP_TCH = 64;           // generic path: query terms looked up per round
-constexpr int SP_TMAX = 12;          // pipelined path: max query terms
-constexpr int SP_PW = SP_WAVES - 1;   // pipelined path: posting waves (wave 0 runs the directory instead)
-constexpr int SP_K = 8;              // pipelined path: 64-posting chunks per posting wave held in registers per segment
-constexpr int SP_NCH = 256;          // pipelined path: chunk-table capacity per segment
+constexpr int SP_TG = 16;            // query terms per group (one 16-lane DPP row)
+constexpr int SP_K = 2;              // pipelined path: chunks per wave held in registers per segment
+constexpr int SP_TCH = 64;           // k_sparse_order: term-count buckets
+constexpr int SP_TCACHE = 256;       // query terms whose table row is resolved once per workgroup
 constexpr double SP_FIX = 1099511627776.0;          // 2^40
 constexpr float SP_UNFIX = 9.094947017729282e-13f;  // 2^-40 (exact in fp32)
-
-__host__ __device__ inline uint64_t sp_hash(uint64_t x) {
-  x ^= x >> 33;
-  x *= 0xff51afd7ed558ccdull;
-  x ^= x >> 33;
-  x *= 0xc4ceb9fe1a85ec53ull;
-  x ^= x >> 33;
-  return x;
-}
 
 // An accumulator word is sum(fx_t) + k * 2^52, k = number of postings added: non-zero
 // exactly when the document was touched, whatever the signs of the products.  Decodes
@@ -92,22 +74,15 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-struct SpChunk {
-  uint32_t off;        // first posting of the chunk
-  uint32_t rem_term;   // postings in the chunk (1..64) | query-term index << 8
-};
 struct SpShared {
   union {
     unsigned long long acc[SEG_DOCS];        // marked fixed-point score per document of the segment
     uint64_t sort[SEG_DOCS];                 // sort scratch while acc is all zero
   };
-  uint32_t t_off[SP_TCH], t_len[SP_TCH];     // generic path: directory of the current segment
-  float t_w[SP_TCH];
-  SpChunk chunk[3][SP_NCH];                  // pipelined path: chunk tables, ring of 3 segments
-  uint32_t nchunks[3], total[3];
   int cnt;                                   // candidates in the workgroup's global buffer
   int trig;                                  // cnt at which the buffer is sorted and cut
   float tau;
+  int ti[SP_TCACHE];                         // live-term index of the query's first SP_TCACHE terms
 };
 // One object at namespace scope: every access is provably LDS (ds_* instructions).  Passed
 // around by reference, hipcc fell back to FLAT addressing for part of the accesses, and a
@@ -239,249 +214,205 @@ __device__ __forceinline__ void sp_finish(const SparseQueryArgs& a, uint64_t* ca
 }
 
 // ---------------------------------------------------------------------------------
-// directory probes (inline-asm loads: untracked by hipcc, retired by counted waits)
+// directory: per-lane run offsets -> wave-uniform chunks
 // ---------------------------------------------------------------------------------
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct Probe {
-  u32x4 r0, r1;   // the two 16-byte table slots fetched speculatively: {key lo, key hi, off, len}
+struct SpDir {            // lane (l & 15) = term slot of the group; all four rows hold the same values
+  uint32_t p0, len, incl;  // first posting / postings / inclusive chunk count up to this term
 };
-__device__ __forceinline__ Probe sp_probe_issue(const SparseQueryArgs& a, int seg, uint32_t term) {
-  Probe p;
-  const uint64_t key = ((uint64_t)seg << 31) | term;
-  const uint64_t slot = sp_hash(key) & a.ix.table_mask;
-  const SpHashEntry* p0 = a.ix.table + slot;
-  const SpHashEntry* p1 = a.ix.table + ((slot + 1) & a.ix.table_mask);
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(p.r0) : "v"(p0) : "memory");
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(p.r1) : "v"(p1) : "memory");
-  return p;
+// inclusive scan over the 16 lanes of a row (DPP row shifts, zeros shifted in)
+__device__ __forceinline__ uint32_t sp_rowscan(uint32_t v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  return v;
 }
-// wait for EVERYTHING this wave has in flight; the probe registers are operands of the wait
-__device__ __forceinline__ void sp_probe_wait(Probe& p) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(p.r0), "+v"(p.r1)::"memory");
+__device__ __forceinline__ SpDir sp_dir(uint32_t p0, uint32_t p1, bool active, uint32_t& nch, uint32_t& total) {
+  SpDir d;
+  d.p0 = p0;
+  d.len = active ? p1 - p0 : 0u;
+  d.incl = sp_rowscan((d.len + 63u) >> 6);
+  nch = (uint32_t)__builtin_amdgcn_readlane((int)d.incl, 15);
+  total = (uint32_t)__builtin_amdgcn_readlane((int)sp_rowscan(d.len), 15);
+  return d;
 }
-// the probe must have landed (sp_probe_wait or sp_wait_slots)
-__device__ __forceinline__ void sp_probe_resolve(const SparseQueryArgs& a, const Probe& p, int seg, uint32_t term,
-                                                 uint32_t& off, uint32_t& len) {
-  const uint64_t key = ((uint64_t)seg << 31) | term;
-  const uint64_t k0 = ((uint64_t)p.r0.y << 32) | p.r0.x, k1 = ((uint64_t)p.r1.y << 32) | p.r1.x;
-  off = 0;
-  len = 0;
-  if (k0 == key) {
-    off = p.r0.z;
-    len = p.r0.w;
-  } else if (k0 == ~0ull) {
-  } else if (k1 == key) {
-    off = p.r1.z;
-    len = p.r1.w;
-  } else if (k1 == ~0ull) {
-  } else {
-    uint64_t slot = ((sp_hash(key) & a.ix.table_mask) + 2) & a.ix.table_mask;   // rare: longer chain
-    while (true) {
-      u32x4 r;
-      const SpHashEntry* pe = a.ix.table + slot;
-      asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(pe) : "memory");
-      const uint64_t k = ((uint64_t)r.y << 32) | r.x;
-      if (k == key) {
-        off = r.z;
-        len = r.w;
-        break;
+// chunk c of the segment: first posting, postings in it (1..64), query weight.  c < nch.
+__device__ __forceinline__ void sp_chunk(const SpDir& d, float qw_lane, uint32_t c, uint32_t& off, uint32_t& cnt,
+                                         float& qw) {
+  const uint32_t m = (uint32_t)__builtin_amdgcn_ballot_w64(d.incl > c) & 0xFFFFu;
+  const int t = __builtin_ctz(m);                       // m != 0 because c < nch = incl[15]
+  const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)d.len, t);
+  const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)d.incl, t) - ((len + 63u) >> 6);
+  const uint32_t j = (c - start) << 6;
+  off = (uint32_t)__builtin_amdgcn_readlane((int)d.p0, t) + j;
+  cnt = len - j < 64u ? len - j : 64u;
+  qw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qw_lane), t));
+}
+
+// live-term index of `term` (binary search in the ascending list), -1 if absent
+__device__ __forceinline__ int sp_find_term(const SparseIndexView& ix, uint32_t term) {
+  int lo = 0, hi = ix.n_live;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ix.uterms[mid] < term) lo = mid + 1; else hi = mid;
+  }
+  return (lo < ix.n_live && ix.uterms[lo] == term) ? lo : -1;
+}
+
+// chunks [c0, nch) of a segment by stride SP_WAVES, straight from memory (no prefetch):
+// accumulate (HARVEST = false) or exchange-harvest (HARVEST = true)
+template <bool HARVEST>
+__device__ __forceinline__ void sp_chunks_direct(const SparseQueryArgs& a, const SpDir& d, float qw_lane, uint32_t c0,
+                                                 uint32_t nch, int lane, uint64_t* cand, float tau, int64_t gbase) {
+  for (uint32_t c = c0; c < nch; c += SP_WAVES) {
+    uint32_t off, cnt;
+    float qw;
+    sp_chunk(d, qw_lane, c, off, cnt, qw);
+    if ((uint32_t)lane < cnt) {
+      const uint2 p = a.ix.post[off + lane];
+      if (!HARVEST) {
+        atomicAdd(&S.acc[p.x], sp_fix(qw, __builtin_bit_cast(float, p.y)));
+      } else {
+        const unsigned long long x = atomicExch(&S.acc[p.x], 0ull);
+        if (x != 0ull) sp_append(cand, tau, x, gbase + p.x);
       }
-      if (k == ~0ull) break;
-      slot = (slot + 1) & a.ix.table_mask;
     }
   }
 }
 
 // ---------------------------------------------------------------------------------
-// pipelined path: T <= SP_TMAX
+// pipelined path: T <= SP_TG
 // ---------------------------------------------------------------------------------
-// The postings a segment holds for the query are cut into chunks of <= 64 consecutive
-// postings of ONE run (a run of length len gives ceil(len/64) chunks).  Posting wave w takes
-// chunks w-1, w-1 + 3, w-1 + 6, ...: a chunk is wave-uniform, so a lane's posting is simply off + lane
-// and all waves carry the same load whatever the run lengths.
-struct SpSlots {            // one segment's postings held by this thread (SP_K chunks of its wave)
-  uint32_t d[SP_K];         // doc_local exactly as loaded: NOTHING may touch a loaded value before
-  float w[SP_K];            //   the counted wait of the visit that consumes it
-  float q[SP_K];            // query weight of the chunk's term (from LDS)
-  uint32_t valid;           // bit k: slot k holds a posting (from the chunk table, not from the data)
-  uint32_t total, nch;      // block-uniform: postings / chunks of the segment
+// One pipeline stage = everything a wave holds for one future visit.
+struct SpStage {
+  float q[SP_K];            // query weight of the chunk's term
+  uint32_t valid;           // bit k: slot k holds a posting
+  SpDir d;
+  uint32_t nch, total;      // scalar: chunks / postings of the segment
 };
-
-// Every group is EXACTLY 2*SP_K loads per wave (missing chunks load posting 0), so
-// `s_waitcnt vmcnt(2*SP_K)` retires everything older than the youngest group.
-__device__ __forceinline__ void sp_load_slots(const SparseQueryArgs& a, int ring, int wave, int lane, SpSlots& R) {
-  R.total = S.total[ring];
-  R.nch = S.nchunks[ring];
-  R.valid = 0;
-  if (wave == 0) return;   // the directory wave holds no postings (and issues no posting loads)
-#pragma unroll
-  for (int k = 0; k < SP_K; ++k) {
-    const uint32_t c = (uint32_t)(k * SP_PW + wave - 1);
-    uint32_t i = 0;
-    float q = 0.f;
-    if (c < R.nch && c < (uint32_t)SP_NCH) {   // wave-uniform
-      const SpChunk e = S.chunk[ring][c];
-      const bool ok = (uint32_t)lane < (e.rem_term & 0xFFu);
-      i = e.off + (ok ? lane : 0);
-      q = S.t_w[e.rem_term >> 8];
-      R.valid |= (ok ? 1u : 0u) << k;
-    }
-    R.q[k] = q;
-    const uint16_t* pd = a.ix.doc_local + i;
-    const float* pw = a.ix.w + i;
-    asm volatile("global_load_ushort %0, %1, off" : "=v"(R.d[k]) : "v"(pd) : "memory");
-    asm volatile("global_load_dword %0, %1, off" : "=v"(R.w[k]) : "v"(pw) : "memory");
+constexpr int SP_D = 3;                         // visits a load is in flight
+constexpr int SP_LPV = SP_K + 2;                // asm loads per visit per wave: 2 offsets + SP_K postings
+// The loads in flight live in VGPRs hipcc does not allocate: the kernel is built with
+// amdgpu_num_vgpr(SP_NVGPR) and stage j owns v[SP_NVGPR + 6j .. +5] -- named only inside asm
+// strings (and their clobber lists, so the kernel's register count covers them).  hipcc
+// cannot see a pending value, so it cannot copy one before it has landed (it did: the
+// loop-carried copies it inserted for asm OUTPUT operands read registers ahead of the wait).
+// sp_stage_issue: table offsets first, then the postings -- SP_LPV loads in a fixed order.
+// sp_stage_collect: one counted wait (everything but the SP_D - 1 younger visits' loads has
+// landed), then the values move to ordinary registers.
+#define SP_NVGPR 104
+static_assert(SP_K == 2 && SP_D == 3, "register map below");
+#define SP_STAGE_FUNCS(J, R0, R1, R2, R3, R4, R5)                                                          \
+  __device__ __forceinline__ void sp_stage_issue##J(const uint32_t* pl, const uint32_t* ph, const uint2* p0, \
+                                                    const uint2* p1) {                                     \
+    asm volatile("global_load_dword v" #R4 ", %0, off\n\t"                                                 \
+                 "global_load_dword v" #R5 ", %1, off\n\t"                                                 \
+                 "global_load_dwordx2 v[" #R0 ":" #R1 "], %2, off\n\t"                                     \
+                 "global_load_dwordx2 v[" #R2 ":" #R3 "], %3, off"                                         \
+                 :                                                                                         \
+                 : "v"(pl), "v"(ph), "v"(p0), "v"(p1)                                                      \
+                 : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3, "v" #R4, "v" #R5);                        \
+  }                                                                                                        \
+  __device__ __forceinline__ void sp_stage_collect##J(uint32_t (&doc)[SP_K], float (&w)[SP_K], uint32_t& o_lo, \
+                                                      uint32_t& o_hi) {                                    \
+    asm volatile("s_waitcnt vmcnt(%6)\n\t"                                                                 \
+                 "v_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 "\n\tv_mov_b32 %2, v" #R2 "\n\t"          \
+                 "v_mov_b32 %3, v" #R3 "\n\tv_mov_b32 %4, v" #R4 "\n\tv_mov_b32 %5, v" #R5                 \
+                 : "=v"(doc[0]), "=v"(w[0]), "=v"(doc[1]), "=v"(w[1]), "=v"(o_lo), "=v"(o_hi)              \
+                 : "n"(SP_LPV * (SP_D - 1))                                                                \
+                 : "memory");                                                                              \
   }
-}
-// Retire everything older than the youngest group.  The registers of the group being
-// consumed are operands of the wait, so no use of them
-// can be scheduled above it and they stay allocated while the loads are in flight.
-__device__ __forceinline__ void sp_wait_slots(SpSlots& R) {
-  static_assert(SP_K == 8, "operand list below");
-  asm volatile("s_waitcnt vmcnt(%16)"
-               : "+v"(R.d[0]), "+v"(R.d[1]), "+v"(R.d[2]), "+v"(R.d[3]), "+v"(R.d[4]), "+v"(R.d[5]), "+v"(R.d[6]),
-                 "+v"(R.d[7]), "+v"(R.w[0]), "+v"(R.w[1]), "+v"(R.w[2]), "+v"(R.w[3]), "+v"(R.w[4]), "+v"(R.w[5]),
-                 "+v"(R.w[6]), "+v"(R.w[7])
-               : "n"(2 * SP_K)
-               : "memory");
-}
-
-// all 64 lanes of wave 0: publish the chunk table of one segment into ring slot `ring`
-__device__ __forceinline__ void sp_publish(int ring, int tid, int T, uint32_t off, uint32_t len) {
-  const uint32_t n = (len + 63u) >> 6;
-  // inclusive scan over lanes 0..15 (T <= SP_TMAX <= 16) with DPP row shifts: no LDS round trips
-  uint32_t incl = n, tot = len;
-  incl += __builtin_amdgcn_update_dpp(0u, incl, 0x111, 0xF, 0xF, true);   // row_shr:1 (0 shifted in)
-  tot += __builtin_amdgcn_update_dpp(0u, tot, 0x111, 0xF, 0xF, true);
-  incl += __builtin_amdgcn_update_dpp(0u, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
-  tot += __builtin_amdgcn_update_dpp(0u, tot, 0x112, 0xF, 0xF, true);
-  incl += __builtin_amdgcn_update_dpp(0u, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
-  tot += __builtin_amdgcn_update_dpp(0u, tot, 0x114, 0xF, 0xF, true);
-  incl += __builtin_amdgcn_update_dpp(0u, incl, 0x118, 0xF, 0xF, true);   // row_shr:8
-  tot += __builtin_amdgcn_update_dpp(0u, tot, 0x118, 0xF, 0xF, true);
-  const uint32_t start = incl - n;
-  for (uint32_t j = 0; j < n; ++j) {
-    const uint32_t c = start + j;
-    if (c < (uint32_t)SP_NCH) {
-      const uint32_t rem = len - (j << 6);
-      S.chunk[ring][c] = SpChunk{off + (j << 6), (rem < 64u ? rem : 64u) | ((uint32_t)tid << 8)};
-    }
-  }
-  if (tid == T - 1) {
-    S.nchunks[ring] = incl;      // may exceed SP_NCH: the visit then takes the overflow path
-    S.total[ring] = tot;
-  }
-}
-
-__device__ __forceinline__ void sp_tails_accumulate(const SparseQueryArgs& a, int ring, uint32_t nch, int wave,
-                                                    int lane) {
-  if (wave == 0) return;
-  for (uint32_t c = SP_K * SP_PW + wave - 1; c < nch; c += SP_PW) {
-    const SpChunk e = S.chunk[ring][c];
-    if ((uint32_t)lane < (e.rem_term & 0xFFu))
-      atomicAdd(&S.acc[a.ix.doc_local[e.off + lane]], sp_fix(S.t_w[e.rem_term >> 8], a.ix.w[e.off + lane]));
-  }
-}
-__device__ __forceinline__ void sp_tails_harvest(const SparseQueryArgs& a, uint64_t* cand, int ring, uint32_t nch,
-                                                 int wave, int lane, float tau, int64_t gbase) {
-  if (wave == 0) return;
-  for (uint32_t c = SP_K * SP_PW + wave - 1; c < nch; c += SP_PW) {
-    const SpChunk e = S.chunk[ring][c];
-    if ((uint32_t)lane < (e.rem_term & 0xFFu)) {
-      const uint32_t d = a.ix.doc_local[e.off + lane];
-      const unsigned long long x = atomicExch(&S.acc[d], 0ull);
-      if (x != 0ull) sp_append(cand, tau, x, gbase + d);
-    }
-  }
-}
-// a segment with more chunks than the table holds: walk the runs directly
-__device__ __forceinline__ void sp_overflow_accumulate(const SparseQueryArgs& a, int seg, int64_t qb, int T, int tid) {
-  for (int t = 0; t < T; ++t) {
-    const uint32_t term = (uint32_t)a.q_idx[qb + t];
-    Probe p = sp_probe_issue(a, seg, term);
-    uint32_t off, len;
-    sp_probe_wait(p);
-    sp_probe_resolve(a, p, seg, term, off, len);
-    const float qw = a.q_val[qb + t];
-    for (uint32_t i = tid; i < len; i += SP_THREADS)
-      atomicAdd(&S.acc[a.ix.doc_local[off + i]], sp_fix(qw, a.ix.w[off + i]));
-  }
-}
+SP_STAGE_FUNCS(0, 104, 105, 106, 107, 108, 109)
+SP_STAGE_FUNCS(1, 110, 111, 112, 113, 114, 115)
+SP_STAGE_FUNCS(2, 116, 117, 118, 119, 120, 121)
+#undef SP_STAGE_FUNCS
 
 __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t* cand, unsigned long long* park, int q,
                                              int part, int s0, int s1, int64_t qb, int T, int tid) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint32_t my_term = 0;
-  Probe pr{};
-  if (tid < 64) {   // wave 0 owns the directory
-    uint32_t off0 = 0, len0 = 0, off1 = 0, len1 = 0;
-    if (tid < T) {
-      my_term = (uint32_t)a.q_idx[qb + tid];
-      S.t_w[tid] = a.q_val[qb + tid];
-      Probe p0 = sp_probe_issue(a, s0, my_term);
-      Probe p1{};
-      if (s0 + 1 < s1) p1 = sp_probe_issue(a, s0 + 1, my_term);
-      sp_probe_wait(p0);
-      sp_probe_wait(p1);
-      sp_probe_resolve(a, p0, s0, my_term, off0, len0);
-      if (s0 + 1 < s1) sp_probe_resolve(a, p1, s0 + 1, my_term, off1, len1);
-      if (s0 + 2 < s1) pr = sp_probe_issue(a, s0 + 2, my_term);
-    }
-    sp_publish(0, tid, T, off0, len0);
-    sp_publish(1, tid, T, off1, len1);
+  const int ts = lane & 15;
+  // term slot: table row and query weight (absent terms and unused slots are inactive)
+  int ti = -1;
+  float qw_lane = 0.f;
+  if (ts < T) {
+    ti = S.ti[ts];
+    qw_lane = a.q_val[qb + ts];
   }
-  lds_barrier();
-  // Two register sets alternate.  Visit(seg) consumes R = postings(seg), copies the doc ids
-  // the harvest needs, and re-fills R with postings(seg+2): in flight for ~1.5 visits.
-  SpSlots A, Bq;
-  sp_load_slots(a, 0, wave, lane, A);
-  sp_load_slots(a, 1, wave, lane, Bq);
-  unsigned long long npost = 0;
-  SP_STAMP_DECL
+  const bool active = ti >= 0;
+  const uint32_t* row = a.ix.ptr + (int64_t)(active ? ti : 0) * (a.ix.n_segments + 1);
+  const int last = a.ix.n_segments;     // row[last] is the end of the term's postings
+  auto clampi = [&](int x) { return x <= last ? x : last; };
 
-  auto visit = [&](SpSlots& R, int seg, const int ring, const int ring2) {
-    if (wave != 0) sp_wait_slots(R);   // R has landed; one younger group may still be in flight
-    const uint32_t total = __builtin_amdgcn_readfirstlane(R.total), nch = __builtin_amdgcn_readfirstlane(R.nch);
+  // issue the loads of stage J for segment `sx`: offsets of sx + SP_D and sx + SP_D + 1, then the
+  // postings of sx's chunks (directory st.d must be set).  Exactly SP_LPV loads, whatever the
+  // segment holds (a missing chunk loads posting 0).
+  auto issue = [&](auto jc, SpStage& st, int sx) {
+    constexpr int J = decltype(jc)::value;
+    const uint2* pp[SP_K];
+    st.valid = 0;
+#pragma unroll
+    for (int k = 0; k < SP_K; ++k) {
+      const uint32_t c = (uint32_t)(k * SP_WAVES + wave);
+      uint32_t off = 0, cnt = 0;
+      st.q[k] = 0.f;
+      if (c < st.nch) sp_chunk(st.d, qw_lane, c, off, cnt, st.q[k]);   // wave-uniform
+      const bool ok = (uint32_t)lane < cnt;
+      pp[k] = a.ix.post + off + (ok ? lane : 0);
+      st.valid |= (ok ? 1u : 0u) << k;
+    }
+    const uint32_t* pl = row + clampi(sx + SP_D);
+    const uint32_t* ph = row + clampi(sx + SP_D + 1);
+    if constexpr (J == 0) sp_stage_issue0(pl, ph, pp[0], pp[1]);
+    if constexpr (J == 1) sp_stage_issue1(pl, ph, pp[0], pp[1]);
+    if constexpr (J == 2) sp_stage_issue2(pl, ph, pp[0], pp[1]);
+  };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>;
+
+  SpStage st0, st1, st2;
+  {
+    // prologue: directories of the first SP_D segments from plain loads (hipcc waits for them)
+    const uint32_t o0 = row[clampi(s0)], o1 = row[clampi(s0 + 1)], o2 = row[clampi(s0 + 2)], o3 = row[clampi(s0 + 3)];
+    st0.d = sp_dir(o0, o1, active, st0.nch, st0.total);
+    st1.d = sp_dir(o1, o2, active, st1.nch, st1.total);
+    st2.d = sp_dir(o2, o3, active, st2.nch, st2.total);
+    issue(J0{}, st0, s0);
+    issue(J1{}, st1, s0 + 1);
+    issue(J2{}, st2, s0 + 2);
+  }
+  unsigned long long npost = 0;
+
+  auto visit = [&](auto jc, SpStage& st, int seg) {
+    constexpr int J = decltype(jc)::value;
+    uint32_t doc[SP_K], o_lo, o_hi;
+    float w[SP_K];
+    // this stage's loads (issued SP_D visits ago) have landed
+    if constexpr (J == 0) sp_stage_collect0(doc, w, o_lo, o_hi);
+    if constexpr (J == 1) sp_stage_collect1(doc, w, o_lo, o_hi);
+    if constexpr (J == 2) sp_stage_collect2(doc, w, o_lo, o_hi);
     const int64_t gbase = a.ix.id_base + (int64_t)seg * SEG_DOCS;
-    const bool overflow = nch > (uint32_t)SP_NCH;               // scalar, absurdly long runs
-    const bool tails = nch > (uint32_t)(SP_K * SP_PW);          // scalar
-    SP_STAMP(0)
+    const uint32_t total = __builtin_amdgcn_readfirstlane(st.total), nch = __builtin_amdgcn_readfirstlane(st.nch);
+    const SpDir d = st.d;
+    const uint32_t valid = st.valid;
+    const bool tails = nch > (uint32_t)(SP_K * SP_WAVES);          // scalar
     if (total) {   // scalar
       npost += total;
       sp_make_room(a, cand, total, tid);
-      SP_STAMP(1)
-      if (!overflow) {
 #pragma unroll
-        for (int k = 0; k < SP_K; ++k)
-          if ((R.valid >> k) & 1u) atomicAdd(&S.acc[R.d[k]], sp_fix(R.q[k], R.w[k]));
-        if (tails) sp_tails_accumulate(a, ring, nch, wave, lane);
-      }
+      for (int k = 0; k < SP_K; ++k)
+        if ((valid >> k) & 1u) atomicAdd(&S.acc[doc[k]], sp_fix(st.q[k], w[k]));
+      if (tails) sp_chunks_direct<false>(a, d, qw_lane, SP_K * SP_WAVES + wave, nch, lane, cand, 0.f, gbase);
     }
-    SP_STAMP(2)
-    if (tid < 64) {   // chunk table of seg+2 (ring slot last used by seg-1, which everybody has left)
-      uint32_t off = 0, len = 0;
-      if (tid < T && seg + 2 < s1) {
-        sp_probe_wait(pr);          // issued a whole visit ago; this wave has nothing else in flight
-        sp_probe_resolve(a, pr, seg + 2, my_term, off, len);
-        if (seg + 3 < s1) pr = sp_probe_issue(a, seg + 3, my_term);
-      }
-      sp_publish(ring2, tid, T, off, len);
-    }
-    if (total && overflow) sp_overflow_accumulate(a, seg, qb, T, tid);
-    SP_STAMP(3)
+    // refill this stage for seg + SP_D
+    st.d = sp_dir(o_lo, o_hi, active, st.nch, st.total);
+    issue(jc, st, seg + SP_D);
     lds_barrier();                                   // ---- X
-    SP_STAMP(4)
-    uint32_t hd[SP_K];                               // landed values: plain register copies
-    const uint32_t hvalid = R.valid;
-#pragma unroll
-    for (int k = 0; k < SP_K; ++k) hd[k] = R.d[k];
-    sp_load_slots(a, ring2, wave, lane, R);          // postings of seg+2
-    SP_STAMP(5)
     if (total) {
       const uint32_t bound = total < (uint32_t)SEG_DOCS ? total : (uint32_t)SEG_DOCS;
       const uint32_t cnt_now = (uint32_t)__builtin_amdgcn_readfirstlane(S.cnt);
-      if (overflow || cnt_now + bound > (uint32_t)SP_CAND) {   // scalar
+      if (cnt_now + bound > (uint32_t)SP_CAND) {                 // scalar
         sp_harvest(a, cand, park, seg, total, tid);             // sweep; ends with a barrier
       } else {
         const float tau = S.tau;
@@ -489,35 +420,26 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) {
           v[k] = 0ull;
-          if ((hvalid >> k) & 1u) v[k] = atomicExch(&S.acc[hd[k]], 0ull);
+          if ((valid >> k) & 1u) v[k] = atomicExch(&S.acc[doc[k]], 0ull);
         }
 #pragma unroll
         for (int k = 0; k < SP_K; ++k)
-          if (v[k] != 0ull) sp_append(cand, tau, v[k], gbase + hd[k]);
-        if (tails) sp_tails_harvest(a, cand, ring, nch, wave, lane, tau, gbase);
+          if (v[k] != 0ull) sp_append(cand, tau, v[k], gbase + doc[k]);
+        if (tails) sp_chunks_direct<true>(a, d, qw_lane, SP_K * SP_WAVES + wave, nch, lane, cand, tau, gbase);
         lds_barrier();                               // ---- Y
       }
     }
-    SP_STAMP(6)
   };
-
   int seg = s0;
-  for (;;) {   // ring slot of seg = (seg - s0) % 3, register set = (seg - s0) % 2: period 6
+  for (;;) {
     if (seg >= s1) break;
-    visit(A, seg, 0, 2);
+    visit(J0{}, st0, seg);
     if (++seg >= s1) break;
-    visit(Bq, seg, 1, 0);
+    visit(J1{}, st1, seg);
     if (++seg >= s1) break;
-    visit(A, seg, 2, 1);
-    if (++seg >= s1) break;
-    visit(Bq, seg, 0, 2);
-    if (++seg >= s1) break;
-    visit(A, seg, 1, 0);
-    if (++seg >= s1) break;
-    visit(Bq, seg, 2, 1);
+    visit(J2{}, st2, seg);
     ++seg;
   }
-  SP_STAMP_FLUSH
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
   if (tid == 0 && a.stat_postings) atomicAdd(a.stat_postings, npost);
@@ -525,9 +447,9 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
 }
 
 // ---------------------------------------------------------------------------------
-// kernel: pipelined body for short queries, generic loop otherwise
+// kernel: pipelined body for queries of up to 16 terms, grouped loop otherwise
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_score(SparseQueryArgs a) {
+__global__ __launch_bounds__(SP_THREADS, 4) __attribute__((amdgpu_num_vgpr(SP_NVGPR))) void k_sparse_score(SparseQueryArgs a) {
   const int tid = threadIdx.x;
   const int slot = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
   const int q = a.q_order ? a.q_order[slot] : slot;     // heaviest queries first
@@ -545,43 +467,54 @@ __global__ __launch_bounds__(SP_THREADS, 2) void k_sparse_score(SparseQueryArgs 
     S.trig = 2 * a.limit < 256 ? 256 : 2 * a.limit;   // first cut early: it gives the first threshold
     S.tau = -__builtin_inff();
   }
+  for (int i = tid; i < T && i < SP_TCACHE; i += SP_THREADS) S.ti[i] = sp_find_term(a.ix, (uint32_t)a.q_idx[qb + i]);
   __syncthreads();
-  if (T <= SP_TMAX && T > 0 && s0 < s1) {   // block-uniform
+  if (T <= SP_TG && T > 0 && s0 < s1) {   // block-uniform
     sp_body_pipe(a, cand, park, q, part, s0, s1, qb, T, tid);
     return;
   }
+  // grouped loop: 16 terms at a time, no prefetch
+  const int lane = tid & 63, wave = tid >> 6, ts = lane & 15;
   unsigned long long npost = 0;
-  for (int seg = s0; seg < s1; ++seg) {
-    uint32_t total = 0;
+  for (int seg = s0; seg < s1 && T > 0; ++seg) {
+    const int64_t gbase = a.ix.id_base + (int64_t)seg * SEG_DOCS;
+    uint32_t seg_total = 0;
     sp_make_room(a, cand, SEG_DOCS, tid);   // acc is all zero between segments
-    for (int tc = 0; tc < T; tc += SP_TCH) {
-      const int nt = (T - tc) < SP_TCH ? (T - tc) : SP_TCH;
-      if (tid < nt) {
-        const uint32_t term = (uint32_t)a.q_idx[qb + tc + tid];
-        Probe p = sp_probe_issue(a, seg, term);
-        uint32_t off, len;
-        sp_probe_wait(p);
-        sp_probe_resolve(a, p, seg, term, off, len);
-        S.t_off[tid] = off;
-        S.t_len[tid] = len;
-        S.t_w[tid] = a.q_val[qb + tc + tid];
+    for (int pass = 0; pass < 2; ++pass) {  // 0: accumulate every group, 1: harvest every group
+      if (pass == 1) {
+        lds_barrier();
+        if (seg_total == 0) break;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane(S.cnt) + (seg_total < (uint32_t)SEG_DOCS ? seg_total : (uint32_t)SEG_DOCS) >
+            (uint32_t)SP_CAND) {
+          sp_harvest(a, cand, park, seg, seg_total, tid);
+          break;
+        }
       }
-      __syncthreads();
-      for (int t = 0; t < nt; ++t) {
-        const uint32_t len = S.t_len[t], off = S.t_off[t];
-        const float qw = S.t_w[t];
-        total += len;
-        for (uint32_t i = tid; i < len; i += SP_THREADS)
-          atomicAdd(&S.acc[a.ix.doc_local[off + i]], sp_fix(qw, a.ix.w[off + i]));
+      const float tau = S.tau;
+      for (int g0 = 0; g0 < T; g0 += SP_TG) {
+        int ti = -1;
+        float qw_lane = 0.f;
+        if (g0 + ts < T) {
+          ti = g0 + ts < SP_TCACHE ? S.ti[g0 + ts] : sp_find_term(a.ix, (uint32_t)a.q_idx[qb + g0 + ts]);
+          qw_lane = a.q_val[qb + g0 + ts];
+        }
+        const bool active = ti >= 0;
+        const uint32_t* row = a.ix.ptr + (int64_t)(active ? ti : 0) * (nseg + 1);
+        uint32_t nch, total;
+        const SpDir d = sp_dir(row[seg], row[seg + 1], active, nch, total);
+        if (pass == 0) {
+          seg_total += total;
+          sp_chunks_direct<false>(a, d, qw_lane, (uint32_t)wave, nch, lane, cand, 0.f, gbase);
+        } else {
+          sp_chunks_direct<true>(a, d, qw_lane, (uint32_t)wave, nch, lane, cand, tau, gbase);
+        }
       }
-      __syncthreads();  // t_off/t_len are rewritten by the next round
+      if (pass == 1) lds_barrier();
     }
-    if (total) {  // block-uniform
-      npost += total;
-      sp_harvest(a, cand, park, seg, total, tid);
-      __syncthreads();
-    }
+    npost += seg_total;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
   if (tid == 0 && a.stat_postings) atomicAdd(a.stat_postings, npost);
   sp_finish(a, cand, q, part, tid);
 }
@@ -614,12 +547,6 @@ __global__ void k_sparse_order(const int64_t* q_indptr, int B, int* q_order) {
     q_order[atomicAdd(&hist[SP_TCH - T], 1)] = b;
   }
 }
-
-#ifdef HX_SP_STAMP
-extern "C" int hx_debug_sp_stamps(unsigned long long* out_host, int n) {
-  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_sp_stamps), (size_t)n * 8);
-}
-#endif
 
 void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st) {
   if (a.B <= 0) return;

@@ -2,10 +2,13 @@
 //
 // Mirrors Qdrant's sparse index build on upsert of the "sparse" named vector
 // (app/core/vector_store/qdrant/qdrant_handler.py:80-86, 163, 190-193).  Input is the
-// doc-major CSR the ingest path appends; output is the segment-major, term-sorted
-// posting store and the (segment, term) -> (offset, length) table of sparse.hip.
-// The sort itself is rocPRIM's LSD radix sort (stable, so documents stay ascending
-// inside a posting run); everything around it is hand-written.
+// doc-major CSR the ingest path appends; output is the TERM-major posting store of
+// sparse.hip: postings sorted by (term, document), the ascending list of live terms, and a
+// dense [live term x segment] table of posting offsets (so a workgroup that walks the
+// segments in order finds every run by indexing -- no hashing, no probing -- and a term's
+// runs of consecutive segments are adjacent in memory).
+// The sort is rocPRIM's LSD radix sort on the 31-bit term id alone: it is stable and the
+// input is document-major, so documents stay ascending inside a term.
 #include "hx_common.hpp"
 #include "kernels.hpp"
 
@@ -16,15 +19,6 @@
 
 namespace hx {
 
-__host__ __device__ inline uint64_t sp_hash_b(uint64_t x) {
-  x ^= x >> 33;
-  x *= 0xff51afd7ed558ccdull;
-  x ^= x >> 33;
-  x *= 0xc4ceb9fe1a85ec53ull;
-  x ^= x >> 33;
-  return x;
-}
-
 struct DevBuf {
   void* p = nullptr;
   explicit DevBuf(size_t bytes) { HX_HIP(hipMalloc(&p, bytes ? bytes : 16)); }
@@ -34,129 +28,109 @@ struct DevBuf {
   T* as() { return (T*)p; }
 };
 
+// one wave per document: key = term id, payload = (local document index, weight bits)
 __global__ void k_make_pairs(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,
-                             uint64_t* keys, uint64_t* pay) {
+                             uint32_t* keys, uint64_t* pay) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (d >= n_docs) return;
   const int64_t b = indptr[d], e = indptr[d + 1];
-  const uint64_t seg = (uint64_t)(d / SEG_DOCS), dl = (uint64_t)(d % SEG_DOCS);
   for (int64_t i = b + lane; i < e; i += 64) {
-    keys[i] = (seg << 31) | (uint64_t)(uint32_t)idx[i];
+    keys[i] = (uint32_t)idx[i];
     uint32_t wb;
     const float w = val[i];
     __builtin_memcpy(&wb, &w, 4);
-    pay[i] = (dl << 32) | wb;
+    pay[i] = ((uint64_t)d << 32) | wb;
   }
 }
 
-__global__ void k_split(const uint64_t* pay, int64_t nnz, uint16_t* doc_local, float* w) {
+// sorted payloads -> postings {document index inside its segment, weight bits}
+__global__ void k_make_postings(const uint64_t* pay, int64_t nnz, uint2* post) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
   const uint64_t p = pay[i];
-  doc_local[i] = (uint16_t)(p >> 32);
-  const uint32_t wb = (uint32_t)p;
-  float f;
-  __builtin_memcpy(&f, &wb, 4);
-  w[i] = f;
+  post[i] = make_uint2((uint32_t)(p >> 32) % (uint32_t)SEG_DOCS, (uint32_t)p);
 }
 
-__global__ void k_table_clear(SpHashEntry* t, uint64_t cap) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cap) {
-    t[i].key = ~0ull;
-    t[i].off = 0;
-    t[i].len = 0;
+// one workgroup per live term: ptr[t][s] = first posting of the term's run [b, e) whose document
+// is >= s * SEG_DOCS (binary search over the sorted payloads), s = 0 .. nseg
+__global__ __launch_bounds__(256) void k_fill_ptr(const uint64_t* pay, const uint64_t* run_off,
+                                                  const uint32_t* run_len, int nseg, uint32_t* ptr) {
+  const int64_t t = blockIdx.x;
+  const uint64_t b = run_off[t], e = b + run_len[t];
+  uint32_t* row = ptr + t * (int64_t)(nseg + 1);
+  for (int s = threadIdx.x; s <= nseg; s += 256) {
+    const uint64_t first_doc = (uint64_t)s * SEG_DOCS;
+    uint64_t lo = b, hi = e;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if ((pay[mid] >> 32) < first_doc) lo = mid + 1; else hi = mid;
+    }
+    row[s] = (uint32_t)lo;
   }
-}
-
-__global__ void k_table_insert(const uint64_t* ukeys, const uint32_t* counts, const uint64_t* offs,
-                               int64_t n_groups, SpHashEntry* t, uint64_t mask) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_groups) return;
-  const uint64_t key = ukeys[g];
-  uint64_t slot = sp_hash_b(key) & mask;
-  while (true) {
-    const unsigned long long prev =
-        atomicCAS((unsigned long long*)&t[slot].key, ~0ull, (unsigned long long)key);
-    if (prev == ~0ull) break;  // keys are unique: nobody else inserts `key`
-    slot = (slot + 1) & mask;
-  }
-  t[slot].off = (uint32_t)offs[g];
-  t[slot].len = counts[g];
 }
 
 void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,
                         int64_t nnz, SparseBuildOut* out, hipStream_t st) {
-  out->doc_local = nullptr;
-  out->w = nullptr;
-  out->table = nullptr;
-  out->table_cap = 0;
-  out->n_groups = 0;
+  *out = SparseBuildOut{};
   if (nnz <= 0 || n_docs <= 0) return;
   HX_CHECK(nnz < (int64_t)0xFFFFFFFFll, "sparse index: nnz per shard must be < 2^32");
+  HX_CHECK(n_docs < (int64_t)0xFFFFFFFFll, "sparse index: documents per shard must be < 2^32");
   const int64_t nseg = (n_docs + SEG_DOCS - 1) / SEG_DOCS;
-  int seg_bits = 1;
-  while ((1ll << seg_bits) < nseg) ++seg_bits;
 
-  DevBuf k_in(nnz * 8), k_out(nnz * 8), p_in(nnz * 8), p_out(nnz * 8);
+  DevBuf k_in(nnz * 4), k_out(nnz * 4), p_in(nnz * 8), p_out(nnz * 8);
   hipLaunchKernelGGL(k_make_pairs, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, indptr, idx, val,
-                     n_docs, k_in.as<uint64_t>(), p_in.as<uint64_t>());
+                     n_docs, k_in.as<uint32_t>(), p_in.as<uint64_t>());
   HX_HIP(hipGetLastError());
 
   size_t tmp_bytes = 0;
-  HX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(),
-                                   p_in.as<uint64_t>(), p_out.as<uint64_t>(), (size_t)nnz, 0u,
-                                   (unsigned)(31 + seg_bits), st));
+  HX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in.as<uint32_t>(), k_out.as<uint32_t>(),
+                                   p_in.as<uint64_t>(), p_out.as<uint64_t>(), (size_t)nnz, 0u, 31u, st));
   {
     DevBuf tmp(tmp_bytes);
-    HX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(),
-                                     p_in.as<uint64_t>(), p_out.as<uint64_t>(), (size_t)nnz, 0u,
-                                     (unsigned)(31 + seg_bits), st));
+    HX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, k_in.as<uint32_t>(), k_out.as<uint32_t>(),
+                                     p_in.as<uint64_t>(), p_out.as<uint64_t>(), (size_t)nnz, 0u, 31u, st));
     HX_HIP(hipStreamSynchronize(st));
   }
 
-  // run-length encode the sorted keys -> groups
-  DevBuf ukeys(nnz * 8), counts(nnz * 4), nruns(8);
-  HX_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, k_out.as<uint64_t>(), (unsigned int)nnz,
-                                    ukeys.as<uint64_t>(), counts.as<uint32_t>(), nruns.as<uint64_t>(), st));
+  // run-length encode the sorted term ids -> live terms and their posting counts
+  DevBuf uterms(nnz * 4), counts(nnz * 4), nruns(8);
+  HX_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, k_out.as<uint32_t>(), (unsigned int)nnz,
+                                    uterms.as<uint32_t>(), counts.as<uint32_t>(), nruns.as<uint64_t>(), st));
   {
     DevBuf tmp(tmp_bytes);
-    HX_HIP(rocprim::run_length_encode(tmp.p, tmp_bytes, k_out.as<uint64_t>(), (unsigned int)nnz,
-                                      ukeys.as<uint64_t>(), counts.as<uint32_t>(), nruns.as<uint64_t>(),
+    HX_HIP(rocprim::run_length_encode(tmp.p, tmp_bytes, k_out.as<uint32_t>(), (unsigned int)nnz,
+                                      uterms.as<uint32_t>(), counts.as<uint32_t>(), nruns.as<uint64_t>(),
                                       st));
     HX_HIP(hipStreamSynchronize(st));
   }
-  uint64_t n_groups = 0;
-  HX_HIP(hipMemcpy(&n_groups, nruns.p, 8, hipMemcpyDeviceToHost));
+  uint64_t n_live = 0;
+  HX_HIP(hipMemcpy(&n_live, nruns.p, 8, hipMemcpyDeviceToHost));
 
-  DevBuf offs(n_groups * 8);
+  DevBuf offs(n_live * 8);
   HX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, counts.as<uint32_t>(), offs.as<uint64_t>(),
-                                 (uint64_t)0, (size_t)n_groups, rocprim::plus<uint64_t>(), st));
+                                 (uint64_t)0, (size_t)n_live, rocprim::plus<uint64_t>(), st));
   {
     DevBuf tmp(tmp_bytes);
     HX_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, counts.as<uint32_t>(), offs.as<uint64_t>(),
-                                   (uint64_t)0, (size_t)n_groups, rocprim::plus<uint64_t>(), st));
+                                   (uint64_t)0, (size_t)n_live, rocprim::plus<uint64_t>(), st));
     HX_HIP(hipStreamSynchronize(st));
   }
 
-  uint64_t cap = 1024;
-  while (cap < 2 * n_groups) cap <<= 1;
-  HX_HIP(hipMalloc((void**)&out->table, cap * sizeof(SpHashEntry)));
-  hipLaunchKernelGGL(k_table_clear, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, out->table, cap);
-  hipLaunchKernelGGL(k_table_insert, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st,
-                     ukeys.as<uint64_t>(), counts.as<uint32_t>(), offs.as<uint64_t>(), (int64_t)n_groups,
-                     out->table, cap - 1);
+  const int64_t ptr_entries = (int64_t)n_live * (nseg + 1);
+  HX_HIP(hipMalloc((void**)&out->ptr, (size_t)ptr_entries * 4));
+  hipLaunchKernelGGL(k_fill_ptr, dim3((unsigned)n_live), dim3(256), 0, st, p_out.as<uint64_t>(), offs.as<uint64_t>(),
+                     counts.as<uint32_t>(), (int)nseg, out->ptr);
   HX_HIP(hipGetLastError());
-
-  HX_HIP(hipMalloc((void**)&out->doc_local, nnz * sizeof(uint16_t)));
-  HX_HIP(hipMalloc((void**)&out->w, nnz * sizeof(float)));
-  hipLaunchKernelGGL(k_split, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p_out.as<uint64_t>(), nnz,
-                     out->doc_local, out->w);
+  HX_HIP(hipMalloc((void**)&out->uterms, (size_t)n_live * 4));
+  HX_HIP(hipMemcpyAsync(out->uterms, uterms.p, (size_t)n_live * 4, hipMemcpyDeviceToDevice, st));
+  HX_HIP(hipMalloc((void**)&out->post, (size_t)nnz * sizeof(uint2)));
+  hipLaunchKernelGGL(k_make_postings, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p_out.as<uint64_t>(),
+                     nnz, out->post);
   HX_HIP(hipGetLastError());
   HX_HIP(hipStreamSynchronize(st));
-  out->table_cap = cap;
-  out->n_groups = (int64_t)n_groups;
+  out->n_live = (int64_t)n_live;
+  out->ptr_entries = ptr_entries;
 }
 
 // ---- synthetic docs (oracle.synth_sparse_docs) ------------------------------------
