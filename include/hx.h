@@ -168,6 +168,7 @@ typedef struct hx_stats {
   int64_t bytes_dense_f32, bytes_dense_f16, bytes_i8, bytes_prefix, bytes_sparse;
   int64_t dense_fallback_queries;   /* queries whose certificate failed so far */
   int64_t i8_fallback_queries;
+  int64_t retry_queries;            /* queries re-run with the safe geometry (overflow, underflow, certificate) */
 } hx_stats;
 int hx_get_stats(hx_index* h, hx_stats* out);
 /* HIP-event profile of the hot kernels, measured on the stream they run on.

@@ -37,7 +37,7 @@ class HxStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_rows", "nnz", "n_segments", "n_groups", "hash_capacity", "bytes_dense_f32",
         "bytes_dense_f16", "bytes_i8", "bytes_prefix", "bytes_sparse",
-        "dense_fallback_queries", "i8_fallback_queries")]
+        "dense_fallback_queries", "i8_fallback_queries", "retry_queries")]
 
 
 class HxProf(C.Structure):

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -87,7 +88,8 @@ struct hx_index {
   int n_segments = 0;
   int64_t sp_docs_built = 0;
   Workspace ws;
-  int64_t dense_fallbacks = 0, i8_fallbacks = 0;
+  int64_t dense_fallbacks = 0, i8_fallbacks = 0, retries = 0;
+  int scan_logcap = SCAN8_LOGCAP;   // entries per wave log (HX_DEBUG_SCAN8_LOGCAP shrinks it: tests)
   // optional HIP-event profile of the scan / sparse kernels (hx_profile)
   struct ProfRec { hipEvent_t a, b; int what; double flops, bytes; };
   bool prof = false;
@@ -331,7 +333,7 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
     hitcnt = (int*)h->ws.get(WS_HITCNT, (size_t)SCAN8_WAVES * 4);
   }
   a.hitcnt = hitcnt;
-  a.logcap = SCAN8_LOGCAP;
+  a.logcap = h->scan_logcap;
   int* kept = (int*)h->ws.get(WS_KEPT, (size_t)B * 4);
   HX_HIP(hipMemsetAsync(kept, 0, (size_t)B * 4, st));
   int64_t r0 = 0, r1 = std::min<int64_t>(h->n, g.C);
@@ -427,6 +429,7 @@ template <typename F>
 static void retry_subset(hx_index* h, const float* q_dev, const std::vector<int>& sel, int L,
                          uint64_t* out_keys, int* out_cnt, hipStream_t st, int level, F&& run) {
   const int ns = (int)sel.size();
+  h->retries += ns;
   const int off = 1000 * (level + 1);
   float* qs = (float*)h->ws.get(WS_H_QD + off, (size_t)ns * h->dim * 4);
   uint64_t* ks = (uint64_t*)h->ws.get(WS_H_OUT + off, (size_t)ns * L * 8);
@@ -751,6 +754,10 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
       throw Error("matryoshka sizes must be ascending multiples of 64, <= dim");
     }
     h->psize[i] = msizes[i];
+  }
+  if (const char* e = getenv("HX_DEBUG_SCAN8_LOGCAP")) {   // tests: force the log-overflow path
+    const int v = atoi(e);
+    if (v >= 1 && v <= SCAN8_LOGCAP) h->scan_logcap = v;
   }
   h->set_device();
   *out = h;
@@ -1084,6 +1091,7 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   out->bytes_sparse = h->nnz * 8 + h->sp.ptr_entries * 4 + h->sp.n_live * 4;
   out->dense_fallback_queries = h->dense_fallbacks;
   out->i8_fallback_queries = h->i8_fallbacks;
+  out->retry_queries = h->retries;
   HX_CATCH
 }
 

@@ -42,6 +42,19 @@
 
 namespace hx {
 
+// Diagnostic build only (-DHX_SP_STAMP): lane 0 of waves 0 and 3 accumulate s_memtime deltas per
+// phase into a debug buffer of its own (never read by the kernel, never in a timed build).
+#ifdef HX_SP_STAMP
+__device__ unsigned long long g_sp_stamps[2 * 8 * 4096];
+#define SP_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SP_STAMP(i) { const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; }
+#define SP_STAMP_FLUSH if ((tid == 0 || tid == 192) && blockIdx.x < 4096) for (int i_ = 0; i_ < 8; ++i_) g_sp_stamps[(blockIdx.x * 2 + (tid != 0)) * 8 + i_] = st_acc[i_];
+#else
+#define SP_STAMP_DECL
+#define SP_STAMP(i)
+#define SP_STAMP_FLUSH
+#endif
+
 constexpr int SP_THREADS = 512;
 constexpr int SP_WAVES = SP_THREADS / 64;
 constexpr int SP_TG = 16;            // query terms per group (one 16-lane DPP row)
@@ -227,13 +240,16 @@ __device__ __forceinline__ uint32_t sp_rowscan(uint32_t v) {
   v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xF, 0xF, true);   // row_shr:8
   return v;
 }
+// total: postings of the segment -- exact (EXACT) or the upper bound 64 * nch
+template <bool EXACT = true>
 __device__ __forceinline__ SpDir sp_dir(uint32_t p0, uint32_t p1, bool active, uint32_t& nch, uint32_t& total) {
   SpDir d;
   d.p0 = p0;
   d.len = active ? p1 - p0 : 0u;
   d.incl = sp_rowscan((d.len + 63u) >> 6);
   nch = (uint32_t)__builtin_amdgcn_readlane((int)d.incl, 15);
-  total = (uint32_t)__builtin_amdgcn_readlane((int)sp_rowscan(d.len), 15);
+  if (EXACT) total = (uint32_t)__builtin_amdgcn_readlane((int)sp_rowscan(d.len), 15);
+  else total = nch << 6;
   return d;
 }
 // chunk c of the segment: first posting, postings in it (1..64), query weight.  c < nch.
@@ -375,14 +391,23 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
   {
     // prologue: directories of the first SP_D segments from plain loads (hipcc waits for them)
     const uint32_t o0 = row[clampi(s0)], o1 = row[clampi(s0 + 1)], o2 = row[clampi(s0 + 2)], o3 = row[clampi(s0 + 3)];
-    st0.d = sp_dir(o0, o1, active, st0.nch, st0.total);
-    st1.d = sp_dir(o1, o2, active, st1.nch, st1.total);
-    st2.d = sp_dir(o2, o3, active, st2.nch, st2.total);
+    st0.d = sp_dir<false>(o0, o1, active, st0.nch, st0.total);
+    st1.d = sp_dir<false>(o1, o2, active, st1.nch, st1.total);
+    st2.d = sp_dir<false>(o2, o3, active, st2.nch, st2.total);
     issue(J0{}, st0, s0);
     issue(J1{}, st1, s0 + 1);
     issue(J2{}, st2, s0 + 2);
   }
-  unsigned long long npost = 0;
+  // The candidate count and the threshold live in LDS (S.cnt, S.tau); a visit works from scalar
+  // copies: `ub` >= S.cnt (every posting of a visit could become a candidate) and `tau_r` <=
+  // S.tau (a stale threshold only lets more candidates through).  They are refreshed where the
+  // buffer may have to be cut: the first visits (early cuts give the first threshold), every 8th
+  // visit, and whenever `ub` says the visit might not fit.
+  uint32_t npost_lane = 0;            // postings of this lane's term (rows 0 only count)
+  uint32_t ub = 0;
+  float tau_r = -__builtin_inff();
+  int nvis = 0;
+  SP_STAMP_DECL
 
   auto visit = [&](auto jc, SpStage& st, int seg) {
     constexpr int J = decltype(jc)::value;
@@ -392,30 +417,42 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
     if constexpr (J == 0) sp_stage_collect0(doc, w, o_lo, o_hi);
     if constexpr (J == 1) sp_stage_collect1(doc, w, o_lo, o_hi);
     if constexpr (J == 2) sp_stage_collect2(doc, w, o_lo, o_hi);
+    SP_STAMP(0)
     const int64_t gbase = a.ix.id_base + (int64_t)seg * SEG_DOCS;
     const uint32_t total = __builtin_amdgcn_readfirstlane(st.total), nch = __builtin_amdgcn_readfirstlane(st.nch);
     const SpDir d = st.d;
     const uint32_t valid = st.valid;
     const bool tails = nch > (uint32_t)(SP_K * SP_WAVES);          // scalar
+    const uint32_t bound = total < (uint32_t)SEG_DOCS ? total : (uint32_t)SEG_DOCS;
+    bool fast = true;
     if (total) {   // scalar
-      npost += total;
-      sp_make_room(a, cand, total, tid);
+      npost_lane += d.len;
+      if (nvis < 16 || (nvis & 7) == 0 || ub + bound > (uint32_t)SP_CAND) {   // scalar
+        sp_make_room(a, cand, total, tid);
+        ub = (uint32_t)__builtin_amdgcn_readfirstlane(S.cnt);
+        tau_r = S.tau;
+      }
+      ++nvis;
+      fast = ub + bound <= (uint32_t)SP_CAND;
+      ub += bound;
 #pragma unroll
       for (int k = 0; k < SP_K; ++k)
         if ((valid >> k) & 1u) atomicAdd(&S.acc[doc[k]], sp_fix(st.q[k], w[k]));
       if (tails) sp_chunks_direct<false>(a, d, qw_lane, SP_K * SP_WAVES + wave, nch, lane, cand, 0.f, gbase);
     }
+    SP_STAMP(1)
     // refill this stage for seg + SP_D
-    st.d = sp_dir(o_lo, o_hi, active, st.nch, st.total);
+    st.d = sp_dir<false>(o_lo, o_hi, active, st.nch, st.total);
     issue(jc, st, seg + SP_D);
+    SP_STAMP(2)
     lds_barrier();                                   // ---- X
+    SP_STAMP(3)
     if (total) {
-      const uint32_t bound = total < (uint32_t)SEG_DOCS ? total : (uint32_t)SEG_DOCS;
-      const uint32_t cnt_now = (uint32_t)__builtin_amdgcn_readfirstlane(S.cnt);
-      if (cnt_now + bound > (uint32_t)SP_CAND) {                 // scalar
+      if (!fast) {                                              // scalar
         sp_harvest(a, cand, park, seg, total, tid);             // sweep; ends with a barrier
+        ub = (uint32_t)__builtin_amdgcn_readfirstlane(S.cnt);
+        tau_r = S.tau;
       } else {
-        const float tau = S.tau;
         unsigned long long v[SP_K];
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) {
@@ -424,9 +461,11 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
         }
 #pragma unroll
         for (int k = 0; k < SP_K; ++k)
-          if (v[k] != 0ull) sp_append(cand, tau, v[k], gbase + doc[k]);
-        if (tails) sp_chunks_direct<true>(a, d, qw_lane, SP_K * SP_WAVES + wave, nch, lane, cand, tau, gbase);
+          if (v[k] != 0ull) sp_append(cand, tau_r, v[k], gbase + doc[k]);
+        if (tails) sp_chunks_direct<true>(a, d, qw_lane, SP_K * SP_WAVES + wave, nch, lane, cand, tau_r, gbase);
+        SP_STAMP(4)
         lds_barrier();                               // ---- Y
+        SP_STAMP(5)
       }
     }
   };
@@ -440,9 +479,10 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
     visit(J2{}, st2, seg);
     ++seg;
   }
+  SP_STAMP_FLUSH
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
-  if (tid == 0 && a.stat_postings) atomicAdd(a.stat_postings, npost);
+  if (tid < 16 && a.stat_postings && npost_lane) atomicAdd(a.stat_postings, (unsigned long long)npost_lane);
   sp_finish(a, cand, q, part, tid);
 }
 
@@ -547,6 +587,12 @@ __global__ void k_sparse_order(const int64_t* q_indptr, int B, int* q_order) {
     q_order[atomicAdd(&hist[SP_TCH - T], 1)] = b;
   }
 }
+
+#ifdef HX_SP_STAMP
+extern "C" int hx_debug_sp_stamps(unsigned long long* out_host, int n) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_sp_stamps), (size_t)n * 8);
+}
+#endif
 
 void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st) {
   if (a.B <= 0) return;

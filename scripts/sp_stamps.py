@@ -1,9 +1,8 @@
-"""Diagnostic: per-phase cycle shares of k_sparse_score (builds a -DHX_SP_STAMP library)."""
+"""Diagnostic: per-phase cycle shares of k_sparse_score (needs the -DHX_SP_STAMP library built in-tree:
+python -c "from rag_application_amd import build; build.build(defines=('HX_SP_STAMP',), lib='rag_application_amd/csrc/build/libhx_stamp.so', objdir='rag_application_amd/csrc/build/stamp')")"""
 import os, sys, ctypes, numpy as np
 sys.path.insert(0, '.')
-from rag_application_amd import build
-lib = build.build(defines=("HX_SP_STAMP",), lib="/tmp/libhx_stamp.so", objdir="/tmp/hx_stamp_obj")
-os.environ["HX_LIB_PATH"] = lib
+os.environ["HX_LIB_PATH"] = os.path.abspath("rag_application_amd/csrc/build/libhx_stamp.so")
 import torch
 from rag_application_amd import engine as eng, synth, _lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
@@ -16,24 +15,15 @@ t = [torch.from_numpy(a).cuda() for a in (qip, qix, qv)]
 for _ in range(2): ix.search_sparse(*t, 100)
 torch.cuda.synchronize()
 import time; t0=time.time(); ix.search_sparse(*t, 100); torch.cuda.synchronize(); print("sparse ms", (time.time()-t0)*1e3, "segments", ix.stats()["n_segments"])
-buf = np.zeros(8*1024, np.uint64)
+buf = np.zeros(2*8*1024, np.uint64)
 _lib.lib().hx_debug_sp_stamps.argtypes=[ctypes.c_void_p, ctypes.c_int]
-rc = _lib.lib().hx_debug_sp_stamps(buf.ctypes.data, 8*1024); assert rc == 0
-st = buf.reshape(1024, 8).astype(np.float64)
-names = ["wait-slots", "make-room", "adds(+tails)", "probe+publish", "barrier X", "load-issue", "harvest+Y", "-"]
+rc = _lib.lib().hx_debug_sp_stamps(buf.ctypes.data, 2*8*1024); assert rc == 0
+st = buf.reshape(1024, 2, 8).astype(np.float64)
+names = ["collect-wait", "room+adds", "dir+issue", "barrier X", "harvest", "barrier Y"]
 nseg = ix.stats()["n_segments"]
-tot = st.sum(1)
-print("cycles per visit: mean %.0f  p50 %.0f  max %.0f" % (tot.mean()/nseg, np.median(tot)/nseg, tot.max()/nseg))
-for i, n in enumerate(names[:7]):
-    print("%-16s mean %.0f  max-block %.0f  (%.1f%%)" % (n, st[:, i].mean()/nseg, st[:, i].max()/nseg, 100*st[:, i].sum()/tot.sum()))
-for i, n in enumerate(names[:7]):
-    v = st[:, i] / nseg
-    print("%-16s p10 %.0f p50 %.0f p90 %.0f p99 %.0f" % (n, *np.percentile(v, [10, 50, 90, 99])))
-T = np.diff(qip)
-# postings per visit per query (from the CSR of the corpus is not available here): use T as proxy
-for tt in range(3, 13):
-    m = T == tt
-    if m.any(): print("T=%2d  n=%3d  cycles/visit mean %.0f  adds %.0f probe %.0f harvest %.0f" % (tt, m.sum(), tot[m].mean()/nseg, st[m,2].mean()/nseg, st[m,3].mean()/nseg, st[m,6].mean()/nseg))
-order = np.argsort(tot)
-print("slowest blocks: T=", T[order[-5:]], "cycles/visit", (tot[order[-5:]]/nseg).astype(int))
-print("fastest blocks: T=", T[order[:5]], "cycles/visit", (tot[order[:5]]/nseg).astype(int))
+for w, wn in ((0, "wave 0"), (1, "wave 3")):
+    s = st[:, w, :6]
+    tot = s.sum(1)
+    print(wn, "ticks per visit: mean %.0f  p50 %.0f  max %.0f  (s_memtime ticks, 100 MHz? see guide)" % (tot.mean()/nseg, np.median(tot)/nseg, tot.max()/nseg))
+    for i, n in enumerate(names):
+        print("  %-14s mean %.1f  p10 %.1f p90 %.1f  (%.1f%%)" % (n, s[:, i].mean()/nseg, np.percentile(s[:, i], 10)/nseg, np.percentile(s[:, i], 90)/nseg, 100*s[:, i].sum()/tot.sum()))

@@ -418,3 +418,88 @@ def test_sparse_cold_paths(eng, torch_mod):
             es, ei = ora.search_sparse(np.asarray(ti, np.int64), np.asarray(tv, np.float32), limit)
             assert_list_equal(s[b], i[b], c[b], es, ei, f"sparse cold b={b} L={limit}")
     ix.close()
+
+
+# ---- the 256 x 256 scan kernel (batches of more than 128 queries) --------------------------------
+def _c_expected_dense(X, Q, limit, prefix=0):
+    """Exact lists from the C restatement (validated against the numpy oracle on the CPU tier)."""
+    from oracle import c_oracle as CO
+    d = prefix or None
+    Xn = CO.cosine_preprocess(X, d)
+    Qn = CO.cosine_preprocess(Q, d)
+    return CO.search_dense(Xn, Qn, limit)
+
+
+@pytest.mark.parametrize("B,limit,prefix", [(300, 10, 0), (257, 100, 0), (300, 100, 64), (200, 40, 128)])
+def test_scan8_large_batch(eng, torch_mod, B, limit, prefix):
+    """Batches above 128 queries take scan8.hip (several chunks, partial last row tile, padded
+    query tile, 1/2/12 k-tiles per row): per-wave append logs, predictive thresholds."""
+    n, dim = 70001, 768
+    X = O.synth_dense(41, 0, n, dim)
+    Q = O.synth_dense(42, 0, B, dim) * np.float32(0.6)
+    ix = eng.HxIndex(dim, (64, 128))
+    ix.add(X)
+    es, ei, ec = _c_expected_dense(X, Q, limit, prefix)
+    keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit, prefix)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"scan8 dense b={b}")
+    ix.close()
+
+
+def test_scan8_i8_large_batch(eng, torch_mod):
+    from oracle import c_oracle as CO
+    n, dim, B, limit = 50000, 768, 260, 40
+    X = O.cosine_preprocess(O.synth_dense(43, 0, n, dim))
+    Q = O.cosine_preprocess(O.synth_dense(44, 0, B, dim))
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    X8, rx = CO.quantize_i8(X)
+    Q8, rq = CO.quantize_i8(Q)
+    es, ei, ec = CO.search_i8(X8, rx, Q8, rq, limit)
+    keys, cnt = ix.search_i8(torch_mod.from_numpy(Q).cuda(), limit)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"scan8 i8 b={b}")
+    ix.close()
+
+
+def test_scan8_underflow_retry(eng, torch_mod):
+    """The predictive threshold (rank kq < L' of the rows seen so far) assumes later rows look like
+    earlier ones.  Here the best rows all sit in the first chunk: later chunks append nothing,
+    kq + appended < L', k_compact flags the queries and they are re-run with the classic rule --
+    results stay exact."""
+    n, dim, B, limit = 60000, 256, 200, 10
+    rng = np.random.default_rng(5)
+    Q = O.synth_dense(52, 0, B, dim)
+    X = O.synth_dense(51, 0, n, dim)
+    # rows 0..799: a query plus a little noise -> far above anything random
+    X[:800] = (Q[rng.integers(0, B, 800)] + 0.15 * X[:800]).astype(np.float32)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    es, ei, ec = _c_expected_dense(X, Q, limit)
+    keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"underflow b={b}")
+    assert ix.stats()["retry_queries"] > 0, "the underflow path was not exercised"
+    ix.close()
+
+
+def test_scan8_log_overflow(eng, torch_mod, monkeypatch):
+    """Per-wave append logs of 4 entries overflow at once: affected queries are flagged (never
+    silently truncated), retried and, if need be, answered by the exact fallback."""
+    monkeypatch.setenv("HX_DEBUG_SCAN8_LOGCAP", "4")
+    n, dim, B, limit = 40000, 128, 150, 20
+    X = O.synth_dense(61, 0, n, dim)
+    Q = O.synth_dense(62, 0, B, dim)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    es, ei, ec = _c_expected_dense(X, Q, limit)
+    keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"log overflow b={b}")
+    st = ix.stats()
+    assert st["retry_queries"] > 0
+    ix.close()
