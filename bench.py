@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override corpus rows (testing)")
     ap.add_argument("--batch", type=int, default=0, help="override query batch (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--cpu-rows", type=int, default=4_000_000)
     ap.add_argument("--cpu-queries", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (box share per GPU)")
     return ap.parse_args()

@@ -18,14 +18,16 @@
 //
 // Schedule.  Stream order of half-tiles: g = 4*T + {A0, B0, B1, A1}; slot = g mod 8
 // (8 x 16 KiB ring).  Phase p of k-tile T (P = 4*T + p):
-//     L segment : ds_read the fragments this phase needs, issue the two loads of
-//                 half-tile g = P + 6, s_waitcnt vmcnt(6)   (all but the 3 youngest done)
+//     L segment : ds_read the fragments this phase needs, s_waitcnt vmcnt(4)
+//                 (everything but the two youngest half-tiles has landed)
 //     barrier
-//     M segment : 8 MFMAs -- quadrant C00 (A0,B0), C01 (A0,B1), C11 (A1,B1), C10 (A1,B0)
+//     M segment : the MFMAs of one quadrant -- C00 (A0,B0), C01 (A0,B1), C11 (A1,B1),
+//                 C10 (A1,B0) -- with the two loads of half-tile g = P + 6 issued between them
 //     barrier
 //   reads: p0 A0(T) | p1 B1(T) | p2 A1(T) | p3 B0(T+1)   (B0 stays in registers for 4 phases)
-// RAW: a half-tile read in phase P+1 has g <= P+3, retired by every wave's vmcnt(6) in
-// phase P ahead of a barrier the reader passes.  WAR: half-tile g+8 is issued in phase
+// RAW: a half-tile read in phase P+1 has g <= P+3, retired by every wave's vmcnt(4) in
+// phase P (g = P+4 and P+5 may still be in flight, P+6 is not issued yet) ahead of a barrier
+// the reader passes.  WAR: half-tile g+8 is issued in phase
 // g+2 or later, its slot's last ds_read is in phase <= g (two phases = two barriers apart).
 // Waves 4..7 (wm = 1) run one barrier behind waves 0..3, so on every SIMD one wave is in
 // its M segment while its partner is in its L segment: the matrix pipe never waits for
