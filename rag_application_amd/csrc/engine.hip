@@ -341,7 +341,9 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   while (r0 < h->n) {
     a.row_begin = r0;
     a.row_end = r1;
-    a.hitlog = r0 > 0 ? hitlog : nullptr;   // the first chunk passes every row: atomic-append kernel
+    a.hitlog = r0 > 0 ? hitlog : nullptr;   // the first chunk passes every row: k_scan, one slot per row
+    a.all_pass = (r0 == 0 && r1 - r0 <= g.C) ? 1 : 0;
+    if (a.all_pass) launch_fill_i32(cnt, B, (int)(r1 - r0), st);
     {
       const double rows = (double)(r1 - r0);
       const double elems = kind == KIND_F16 ? (double)row_bytes / 2.0 : (double)row_bytes;
@@ -481,6 +483,7 @@ static void search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     r.cand = cand;
     r.cnt = cnt;
     r.stride = g.C;
+    r.max_cnt = g.Lp;       // chunked_scan's last compaction keeps at most L' keys
     r.B = B;
     r.out = cand2;
     launch_rescore_list(r, st);

@@ -35,6 +35,9 @@ struct ScanArgs {
   uint4* hitlog;           // [SCAN8_WAVES x logcap] {key lo, key hi, query, 0}
   int* hitcnt;             // [SCAN8_WAVES] entries written (may exceed logcap: the rest set overflow[q])
   int logcap;
+  // k_scan only: tau is -inf and rows_end - row_begin <= cap, so every row has its own slot
+  // (row - row_begin, key 0 for a NaN score) and no counter is touched: the caller presets cnt.
+  int all_pass;
 };
 constexpr int SCAN8_WAVES = 256 * 8;   // waves of the largest scan8 grid
 constexpr int SCAN8_LOGCAP = 8192;
@@ -74,6 +77,7 @@ struct RescoreArgs {
   int stride;
   int B;
   uint64_t* out;           // [B x stride]
+  int max_cnt;             // upper bound of cnt[] (0: stride): sizes the grid; slots beyond it are NOT written
 };
 void launch_rescore_list(const RescoreArgs& a, hipStream_t st);
 

@@ -237,11 +237,15 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
           bool hit = false;
 #pragma unroll
           for (int e = 0; e < 16; ++e) hit |= (sc[e] >= tau);
-          if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+          if (a.all_pass || __builtin_amdgcn_ballot_w64(hit) != 0ull) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-              if (sc[e] >= tau && row < a.row_end) {
+              if (a.all_pass) {   // first chunk: slot = row, nothing to count
+                if (qok && row < a.row_end)
+                  g_cand[(int64_t)q * a.cap + (row - a.row_begin)] =
+                      sc[e] >= tau ? make_key(sc[e], (uint32_t)(a.id_base + row)) : 0ull;
+              } else if (sc[e] >= tau && row < a.row_end) {
                 const int pos = __hip_atomic_fetch_add(g_cnt + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (pos < a.cap)
                   g_cand[(int64_t)q * a.cap + pos] = make_key(sc[e], (uint32_t)(a.id_base + row));

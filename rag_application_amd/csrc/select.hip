@@ -10,7 +10,7 @@ namespace hx {
 // compaction: bitonic sort (descending) of <= 8192 keys in LDS, optional dedupe
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ keys, int stride,
-                                                 const int* __restrict__ in_cnt, int P, int keep,
+                                                 const int* __restrict__ in_cnt, int Pmax, int keep,
                                                  int dedupe, uint64_t* out_keys, int out_stride,
                                                  int* out_cnt, float* tau, int tau_rank, int chk_rank,
                                                  int* kept_io, int* underflow) {
@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ ke
   int n = in_cnt ? in_cnt[b] : stride;
   const int n_raw = n;
   n = n < stride ? n : stride;
-  n = n < P ? n : P;
+  n = n < Pmax ? n : Pmax;
+  int P = 256;                       // sort size of THIS list: next power of two >= n (<= Pmax)
+  while (P < n) P <<= 1;
   for (int i = tid; i < P; i += 256) sk[i] = i < n ? keys[(int64_t)b * stride + i] : 0ull;
   __syncthreads();
   for (int k = 2; k <= P; k <<= 1) {
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(256) void k_rescore_list(RescoreArgs a) {
 
 void launch_rescore_list(const RescoreArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.stride <= 0) return;
-  hipLaunchKernelGGL(k_rescore_list, dim3((a.stride + 3) / 4, a.B), dim3(256), 0, st, a);
+  const int m = (a.max_cnt > 0 && a.max_cnt < a.stride) ? a.max_cnt : a.stride;
+  hipLaunchKernelGGL(k_rescore_list, dim3((m + 3) / 4, a.B), dim3(256), 0, st, a);
   HX_HIP(hipGetLastError());
 }
 
