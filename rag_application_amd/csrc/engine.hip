@@ -329,7 +329,7 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   uint4* hitlog = nullptr;
   int* hitcnt = nullptr;
   if (bn == 256) {   // per-wave append logs of the 256 x 256 kernel (scan8.hip)
-    hitlog = (uint4*)h->ws.get(WS_HITLOG, (size_t)SCAN8_WAVES * SCAN8_LOGCAP * sizeof(uint4));
+    hitlog = (uint4*)h->ws.get(WS_HITLOG, (size_t)SCAN8_WAVES * SCAN8_LOGCAP * SCAN8_ENTRY * sizeof(uint4));
     hitcnt = (int*)h->ws.get(WS_HITCNT, (size_t)SCAN8_WAVES * 4);
   }
   a.hitcnt = hitcnt;

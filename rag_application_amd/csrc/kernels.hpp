@@ -32,7 +32,7 @@ struct ScanArgs {
   // scan8 only: per-wave append logs.  A passing (key, query) is stored -- fire and forget -- at
   // hitlog[wave * logcap + i]; launch_scatter_log moves the logs into cand/cnt afterwards.
   // hitlog == NULL (or a launch expected to pass most rows) selects the atomic-append kernel.
-  uint4* hitlog;           // [SCAN8_WAVES x logcap] {key lo, key hi, query, 0}
+  uint4* hitlog;           // [SCAN8_WAVES x logcap x SCAN8_ENTRY]: {query, first row lo, hi, 0} + 16 scores
   int* hitcnt;             // [SCAN8_WAVES] entries written (may exceed logcap: the rest set overflow[q])
   int logcap;
   // k_scan only: tau is -inf and rows_end - row_begin <= cap, so every row has its own slot
@@ -40,7 +40,8 @@ struct ScanArgs {
   int all_pass;
 };
 constexpr int SCAN8_WAVES = 256 * 8;   // waves of the largest scan8 grid
-constexpr int SCAN8_LOGCAP = 8192;
+constexpr int SCAN8_LOGCAP = 4096;      // entries per wave (expected: a few hundred per launch)
+constexpr int SCAN8_ENTRY = 9;          // 16-byte words per entry, sized for the larger (32x32) tile shape
 void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st);
 // scan8.hip: the 256 x 256 staggered-phase kernel behind launch_scan for large batches
 bool scan8_usable(const ScanArgs& a, int bn);

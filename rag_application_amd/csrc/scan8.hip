@@ -37,8 +37,9 @@
 // Appends.  A returning atomic on the per-query counter stalls the wave -- and through the
 // barriers its whole workgroup -- for a memory round trip per passing score (measured: +34 %
 // kernel time at 1,200 passes per query).  Instead every wave owns a log in global memory and
-// writes (key, query) with plain stores at a scalar position it keeps itself; k_scatter_log
-// moves the logs into the per-query candidate buffers after the scan.
+// writes the passing lane's column of scores with plain stores at a scalar position it keeps
+// itself; k_scatter_log picks the passing rows and moves them into the per-query candidate
+// buffers after the scan.
 #include <stdlib.h>
 #include <type_traits>
 #include "hx_common.hpp"
@@ -217,8 +218,9 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 
   // quadrant epilogue: threshold filter; passing (key, query) pairs go to this wave's log
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int S8_ENTRY = 1 + MT * (EPT / 4);   // 16-byte words per log entry
   auto* g_log = (__attribute__((address_space(1))) u32x4*)a.hitlog +
-                (int64_t)(blockIdx.x * 8 + wave) * a.logcap;
+                (int64_t)(blockIdx.x * 8 + wave) * a.logcap * S8_ENTRY;
   int wpos = 0;   // entries this wave has logged (scalar)
   auto filter = [&](int rt, int qt, int ha, int hb, acc_t (&c)[MT][NT]) __attribute__((always_inline)) {
     // lane owns query column r of each of the NT tiles and, per row tile, EPT rows:
@@ -266,34 +268,36 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
       any |= (mm >= tau[nt]);
     }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) == 0ull, 1)) return;
+    // Rare path, kept SHORT (it is inlined in every phase of every k-tile body, and a long one
+    // pushed the kernel far past the instruction cache): a lane whose column reached its
+    // threshold logs the whole column -- {query, first row} + its MT x EPT scores -- with plain
+    // stores; k_scatter_log picks the passing rows.
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool hit = m[nt] >= tau[nt];
+      const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
+      if (mask == 0ull) continue;
+      const int idx = wpos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      if (hit) {
+        const int q = q0 + nt * TS;
+        if (idx < a.logcap) {
+          auto* e = g_log + (int64_t)idx * S8_ENTRY;
+          e[0] = u32x4{(uint32_t)q, (uint32_t)rowq, (uint32_t)((uint64_t)rowq >> 32), 0u};
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          if (__builtin_amdgcn_ballot_w64(gm[nt][mt][g] >= tau[nt]) == 0ull) continue;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int64_t row = rowq + mt * TS + 8 * g + i;
-            const float s = sc[nt][mt][4 * g + i];
-            const bool hit = s >= tau[nt] && row < a.row_end;
-            const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
-            if (mask == 0ull) continue;
-            const int idx = wpos + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (hit) {
-              const int q = q0 + nt * TS;
-              if (idx < a.logcap) {
-                const uint64_t key = make_key(s, (uint32_t)(a.id_base + row));
-                g_log[idx] = u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)q, 0u};
-              } else {
-                g_ovf[q] = 1;
-              }
-            }
-            wpos += __builtin_popcountll(mask);
-          }
+            for (int g = 0; g < NG; ++g)
+              e[1 + mt * NG + g] = u32x4{__builtin_bit_cast(uint32_t, sc[nt][mt][4 * g + 0]),
+                                         __builtin_bit_cast(uint32_t, sc[nt][mt][4 * g + 1]),
+                                         __builtin_bit_cast(uint32_t, sc[nt][mt][4 * g + 2]),
+                                         __builtin_bit_cast(uint32_t, sc[nt][mt][4 * g + 3])};
+        } else {
+          g_ovf[q] = 1;
         }
+      }
+      wpos += __builtin_popcountll(mask);
+    }
   };
 
   // MFMAs of k-steps [ks0, ks1) of one quadrant
@@ -416,22 +420,44 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 #undef S8_WAIT
 }
 
-// one workgroup per wave log: entries -> the per-query candidate buffers (order is irrelevant,
-// k_compact sorts them)
+// one workgroup per wave log: every entry is a lane's column of one quadrant (see the filter);
+// rows whose score reaches the query's threshold go to the per-query candidate buffers (order is
+// irrelevant, k_compact sorts them).  tau is what the scan used: nothing updates it in between.
+template <int TS>
 __global__ __launch_bounds__(256) void k_scatter_log(const uint4* __restrict__ log, const int* __restrict__ hitcnt,
-                                                     int logcap, uint64_t* __restrict__ cand, int* __restrict__ cnt,
-                                                     int* __restrict__ ovf, int cap) {
+                                                     int logcap, const float* __restrict__ tau, int64_t row_end,
+                                                     int64_t id_base, uint64_t* __restrict__ cand,
+                                                     int* __restrict__ cnt, int* __restrict__ ovf, int cap) {
+  constexpr int MT = 64 / TS, EPT = TS * TS / 64, NG = EPT / 4, ENTRY = 1 + MT * NG;
   const int w = blockIdx.x;
   int n = hitcnt[w];
   n = n < logcap ? n : logcap;
+  const uint4* base = log + (int64_t)w * logcap * ENTRY;
   for (int i = threadIdx.x; i < n; i += 256) {
-    const uint4 e = log[(int64_t)w * logcap + i];
-    const int q = (int)e.z;
-    const int pos = atomicAdd(cnt + q, 1);
-    if (pos < cap)
-      cand[(int64_t)q * cap + pos] = ((uint64_t)e.y << 32) | e.x;
-    else
-      ovf[q] = 1;
+    const uint4* e = base + (int64_t)i * ENTRY;
+    const uint4 h = e[0];
+    const int q = (int)h.x;
+    const int64_t row0 = (int64_t)(((uint64_t)h.z << 32) | h.y);
+    const float t = tau[q];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const uint4 v = e[1 + mt * NG + g];
+        const uint32_t bits[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float s = __builtin_bit_cast(float, bits[k]);
+          const int64_t row = row0 + mt * TS + 8 * g + k;
+          if (s >= t && row < row_end) {
+            const int pos = atomicAdd(cnt + q, 1);
+            if (pos < cap)
+              cand[(int64_t)q * cap + pos] = make_key(s, (uint32_t)(id_base + row));
+            else
+              ovf[q] = 1;
+          }
+        }
+      }
   }
 }
 
@@ -461,8 +487,8 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st) {
   else
     hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
   HX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_scatter_log, dim3((unsigned)g * 8), dim3(256), 0, st, a.hitlog, a.hitcnt, a.logcap, a.cand,
-                     a.cnt, a.overflow, a.cap);
+  hipLaunchKernelGGL(k_scatter_log<HX_S8_TS>, dim3((unsigned)g * 8), dim3(256), 0, st, a.hitlog, a.hitcnt, a.logcap,
+                     a.tau, a.row_end, a.id_base, a.cand, a.cnt, a.overflow, a.cap);
   HX_HIP(hipGetLastError());
 }
 

@@ -9,14 +9,15 @@ namespace hx {
 // ---------------------------------------------------------------------------------
 // compaction: bitonic sort (descending) of <= 8192 keys in LDS, optional dedupe
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ keys, int stride,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_compact(const uint64_t* __restrict__ keys, int stride,
                                                  const int* __restrict__ in_cnt, int Pmax, int keep,
                                                  int dedupe, uint64_t* out_keys, int out_stride,
                                                  int* out_cnt, float* tau, int tau_rank, int chk_rank,
                                                  int* kept_io, int* underflow) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint64_t* sk = (uint64_t*)smem;
-  __shared__ int part[256];
+  __shared__ int part[NT];
   __shared__ uint64_t s_kth;
   const int b = blockIdx.x, tid = threadIdx.x;
   int n = in_cnt ? in_cnt[b] : stride;
@@ -25,11 +26,11 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ ke
   n = n < Pmax ? n : Pmax;
   int P = 256;                       // sort size of THIS list: next power of two >= n (<= Pmax)
   while (P < n) P <<= 1;
-  for (int i = tid; i < P; i += 256) sk[i] = i < n ? keys[(int64_t)b * stride + i] : 0ull;
+  for (int i = tid; i < P; i += NT) sk[i] = i < n ? keys[(int64_t)b * stride + i] : 0ull;
   __syncthreads();
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < P; i += 256) {
+      for (int i = tid; i < P; i += NT) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const uint64_t x = sk[i], y = sk[ixj];
@@ -43,11 +44,12 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ ke
       __syncthreads();
     }
   }
-  // flags + block scan (each thread owns P/256 consecutive slots; P >= 256)
-  const int per = P >> 8;
+  // flags + block scan (thread t owns `per` consecutive slots from t*per; threads past P idle)
+  const int per = P >= NT ? P / NT : 1;
   const int base = tid * per;
+  const int mine = base < P ? per : 0;
   int c = 0;
-  for (int e = 0; e < per; ++e) {
+  for (int e = 0; e < mine; ++e) {
     const int i = base + e;
     const uint64_t x = sk[i];
     const bool f = x != 0ull && (!dedupe || i == 0 || x != sk[i - 1]);
@@ -55,19 +57,19 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ ke
   }
   part[tid] = c;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
+  for (int off = 1; off < NT; off <<= 1) {
     const int v = tid >= off ? part[tid - off] : 0;
     __syncthreads();
     part[tid] += v;
     __syncthreads();
   }
-  const int total = part[255];
+  const int total = part[NT - 1];
   int pos = part[tid] - c;
   uint64_t* o = out_keys + (int64_t)b * out_stride;
   // read everything we need before any (possibly aliasing) write: it is all in LDS.
   if (tid == 0) s_kth = 0ull;
   __syncthreads();
-  for (int e = 0; e < per; ++e) {
+  for (int e = 0; e < mine; ++e) {
     const int i = base + e;
     const uint64_t x = sk[i];
     const bool f = x != 0ull && (!dedupe || i == 0 || x != sk[i - 1]);
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint64_t* __restrict__ ke
     }
   }
   const int kept = total < keep ? total : keep;
-  for (int i = kept + tid; i < out_stride; i += 256) o[i] = 0ull;  // empty slots are 0
+  for (int i = kept + tid; i < out_stride; i += NT) o[i] = 0ull;  // empty slots are 0
   __syncthreads();
   if (tid == 0) {
     out_cnt[b] = kept;
@@ -104,14 +106,20 @@ void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int ke
   HX_CHECK(keep <= out_stride, "compact: keep > out_stride");
   static bool attr_set = false;
   if (!attr_set) {
-    HX_HIP(hipFuncSetAttribute((const void*)k_compact, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HX_HIP(hipFuncSetAttribute((const void*)k_compact<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               CAND_CAP * 8));
+    HX_HIP(hipFuncSetAttribute((const void*)k_compact<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                CAND_CAP * 8));
     attr_set = true;
   }
   if (tau_rank <= 0 || tau_rank > keep) tau_rank = keep;
   HX_CHECK(!kept_io || underflow, "compact: kept_io without an underflow flag array");
-  hipLaunchKernelGGL(k_compact, dim3(B), dim3(256), (size_t)P * 8, st, keys, stride, in_cnt, P, keep,
-                     dedupe, out_keys, out_stride, out_cnt, tau, tau_rank, chk_rank, kept_io, underflow);
+  if (P >= 1024)   // long lists: 1024 threads per list (16 of the 66 sort stages of P = 2048 per barrier)
+    hipLaunchKernelGGL(k_compact<1024>, dim3(B), dim3(1024), (size_t)P * 8, st, keys, stride, in_cnt, P, keep,
+                       dedupe, out_keys, out_stride, out_cnt, tau, tau_rank, chk_rank, kept_io, underflow);
+  else
+    hipLaunchKernelGGL(k_compact<256>, dim3(B), dim3(256), (size_t)P * 8, st, keys, stride, in_cnt, P, keep,
+                       dedupe, out_keys, out_stride, out_cnt, tau, tau_rank, chk_rank, kept_io, underflow);
   HX_HIP(hipGetLastError());
 }
 

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
   ScanArgs a{};
   a.A = (const uint8_t*)A; a.Q = (const uint8_t*)Q; a.row_bytes = rb; a.row_begin = 0; a.row_end = rows; a.B = B;
   a.nq_tiles = Bpad / 256; a.tau = tau; a.cand = cand; a.cnt = cnt; a.overflow = ovf; a.cap = 2048; a.id_base = 0;
-  hipMalloc(&a.hitlog, (size_t)SCAN8_WAVES * SCAN8_LOGCAP * 16); hipMalloc(&a.hitcnt, SCAN8_WAVES * 4); a.logcap = SCAN8_LOGCAP;
+  hipMalloc(&a.hitlog, (size_t)SCAN8_WAVES * SCAN8_LOGCAP * SCAN8_ENTRY * 16); hipMalloc(&a.hitcnt, SCAN8_WAVES * 4); a.logcap = SCAN8_LOGCAP;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int w = 0; w < 2; ++w) { if (old) launch_scan(a, KIND_F16, 128, 0); else launch_scan8(a, KIND_F16, 0); }
