@@ -17,18 +17,19 @@
 // ds_read_b128 address -- conflict free, see scan.hip).
 //
 // Schedule.  Stream order of half-tiles: g = 4*T + {A0, B0, B1, A1}; slot = g mod 8
-// (8 x 16 KiB ring).  Phase p of k-tile T (P = 4*T + p):
-//     L segment : ds_read the fragments this phase needs, s_waitcnt vmcnt(4)
-//                 (everything but the two youngest half-tiles has landed)
+// (8 x 16 KiB ring).  A k-tile is two phases of two quadrants each (HX_S8_PH = 2; the
+// one-quadrant-per-phase form, HX_S8_PH = 4, has twice the barriers and measured 5-7 % slower):
+//     L segment : ds_read the fragments this phase needs, one counted s_waitcnt vmcnt
 //     barrier
-//     M segment : the MFMAs of one quadrant -- C00 (A0,B0), C01 (A0,B1), C11 (A1,B1),
-//                 C10 (A1,B0) -- with the two loads of half-tile g = P + 6 issued between them
+//     M segment : the 32 MFMAs of two quadrants with the four loads of half-tiles g+6, g+7
+//                 issued between them
 //     barrier
-//   reads: p0 A0(T) | p1 B1(T) | p2 A1(T) | p3 B0(T+1)   (B0 stays in registers for 4 phases)
-// RAW: a half-tile read in phase P+1 has g <= P+3, retired by every wave's vmcnt(4) in
-// phase P (g = P+4 and P+5 may still be in flight, P+6 is not issued yet) ahead of a barrier
-// the reader passes.  WAR: half-tile g+8 is issued in phase
-// g+2 or later, its slot's last ds_read is in phase <= g (two phases = two barriers apart).
+//   X: reads A0, B0, B1(T) | C00 += A0.B0, C01 += A0.B1 | stages B1, A1 of T+1 | vmcnt(4)
+//   Y: reads A1(T)         | C11 += A1.B1, C10 += A1.B0 | stages A0, B0 of T+2 | vmcnt(2)
+// RAW: the wait of X retires g <= 4T+3 (4T+4, 4T+5 may be in flight), the wait of Y retires
+// g <= 4T+6 (only 4T+7 in flight), each ahead of the barrier before the reading phase.
+// WAR: slot(g) is restaged by g+8 in the M segment of the phase after its last read, i.e.
+// behind one more barrier than the reads (which every wave retires with lgkmcnt(0) first).
 // Waves 4..7 (wm = 1) run one barrier behind waves 0..3, so on every SIMD one wave is in
 // its M segment while its partner is in its L segment: the matrix pipe never waits for
 // LDS reads or load issue.  Per-query thresholds live in LDS (no VGPR-destination global
@@ -56,6 +57,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+#ifndef HX_S8_PH
+#define HX_S8_PH 2   // phases per k-tile: 4 (one quadrant each) or 2 (two quadrants each)
+#endif
 #ifndef HX_S8_TS
 #define HX_S8_TS 16
 #endif
@@ -210,7 +214,9 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   advance(c2);                       // T = 2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#if HX_S8_PH == 4
   read_b(1, bA);
+#endif
   if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger
 
   int cj = i0, c_kt = 0;
@@ -373,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   __builtin_amdgcn_s_barrier();                                                 \
   __builtin_amdgcn_sched_barrier(0);
 
+#if HX_S8_PH == 4
   // one k-tile = four phases.  PAR = T & 1 (ring half and the B register set holding B0).
   auto ktile = [&](auto par_c, auto first_c) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;
@@ -399,6 +406,71 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     c_kt = last ? 0 : c_kt + 1;
     cj += last ? per_xcd : 0;
   };
+#else
+  // Two phases per k-tile, two quadrants each: half the barriers per MFMA.
+  //   X: reads A0, B0, B1 | C00 += A0.B0, C01 += A0.B1 | stages B1, A1 of T+1 | vmcnt(4)
+  //   Y: reads A1         | C11 += A1.B1, C10 += A1.B0 | stages A0, B0 of T+2 | vmcnt(2)
+  // Half-tile g = 4T + {A0, B0, B1, A1} is read in phase X (i < 3) or Y of k-tile T and staged
+  // 6 half-tiles ahead, always in an M segment.  RAW: the wait of X retires g <= 4T+3 (g = 4T+4,
+  // 4T+5 may be in flight), the wait of Y retires g <= 4T+6 (only 4T+7 in flight), each ahead
+  // of the barrier before the reading phase.  WAR: slot(g) is restaged by g+8 in the M segment
+  // of the phase after its last read, i.e. behind one more barrier than the reads.
+#define S8_QUAD(ACC, BF, HA, HB, BASE, KOFF, OFF, SLOT)                         \
+  mma(ACC, BF, FIRST, 0, KS / 2);                                               \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  stage1(BASE, KOFF, OFF, SLOT, 0);                                             \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  mma(ACC, BF, FIRST, KS / 2, KS);                                              \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  stage1(BASE, KOFF, OFF, SLOT, 1);                                             \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  if (__builtin_expect(last, 0)) filter(rt, qt, HA, HB, ACC);
+#define S8_L_END(N)                                                             \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                      \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  __builtin_amdgcn_s_barrier();                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  __builtin_amdgcn_s_setprio(1);
+#define S8_M_END()                                                              \
+  __builtin_amdgcn_s_setprio(0);                                                \
+  __builtin_amdgcn_sched_barrier(0);                                            \
+  __builtin_amdgcn_s_barrier();                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+  auto ktile = [&](auto par_c, auto first_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value;
+    constexpr int S0 = 4 * PAR, N0 = 4 * (1 - PAR);
+    const bool last = (c_kt == KT - 1);
+    int rt = 0, qt = 0;
+    if (last) {
+      const int d = __builtin_amdgcn_readfirstlane(cj / nq);
+      rt = d * 8 + xcd;
+      qt = cj - d * nq;
+    }
+    // phase X
+    read_a(S0 + 0);
+    read_b(S0 + 1, bA);
+    read_b(S0 + 2, bB);
+    S8_L_END(4)
+    S8_QUAD(acc[0][0], bA, 0, 0, c1.q, c1.koff, offB[1], N0 + 2)
+    S8_QUAD(acc[0][1], bB, 0, 1, c1.a, c1.koff, offA[1], N0 + 3)
+    S8_M_END()
+    // phase Y
+    read_a(S0 + 3);
+    S8_L_END(2)
+    S8_QUAD(acc[1][1], bB, 1, 1, c2.a, c2.koff, offA[0], S0 + 0)
+    S8_QUAD(acc[1][0], bA, 1, 0, c2.q, c2.koff, offB[0], S0 + 1)
+    S8_M_END()
+
+    c1 = c2;
+    advance(c2);
+    c_kt = last ? 0 : c_kt + 1;
+    cj += last ? per_xcd : 0;
+  };
+#undef S8_QUAD
+#undef S8_L_END
+#undef S8_M_END
+#endif
   auto ktile_any = [&](auto par_c) __attribute__((always_inline)) {
     if (c_kt == 0)
       ktile(par_c, std::true_type{});
