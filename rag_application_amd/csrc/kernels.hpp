@@ -135,8 +135,11 @@ void launch_prep_queries_i8(const float* q_raw, int q_dim, int B, int Bpad, int 
                             float* rinv_q, hipStream_t st);
 
 // ---- sparse.hip --------------------------------------------------------------
-constexpr int SEG_DOCS = 8192;        // docs per index segment (LDS accumulator: 8 B per doc = 64 KiB)
-constexpr int SP_CAND = 8192;         // per-workgroup candidate buffer (keys, global memory)
+#ifndef HX_SEG_DOCS
+#define HX_SEG_DOCS 8192
+#endif
+constexpr int SEG_DOCS = HX_SEG_DOCS;   // docs per index segment (LDS accumulator: 8 B per doc)
+constexpr int SP_CAND = SEG_DOCS;     // per-workgroup candidate buffer (keys, global memory)
 // Term-major inverted index: the postings of live term i (ascending document) are
 // post[ptr[i*(n_segments+1) + 0] .. ptr[i*(n_segments+1) + n_segments]); ptr[i*(S+1) + s] is
 // the first posting of term i whose document lies in segment s or later.  A posting is

@@ -55,7 +55,10 @@ __device__ unsigned long long g_sp_stamps[2 * 8 * 4096];
 #define SP_STAMP_FLUSH
 #endif
 
-constexpr int SP_THREADS = 512;
+#ifndef HX_SP_THREADS
+#define HX_SP_THREADS 512
+#endif
+constexpr int SP_THREADS = HX_SP_THREADS;
 constexpr int SP_WAVES = SP_THREADS / 64;
 constexpr int SP_TG = 16;            // query terms per group (one 16-lane DPP row)
 constexpr int SP_K = 2;              // pipelined path: chunks per wave held in registers per segment

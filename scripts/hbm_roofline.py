@@ -1,0 +1,26 @@
+"""North-star side measurement: the bandwidth-bound configuration of the same corpus -- dense kNN
+over 10M x 768 with B in {1, 8, 32} queries per pass.  Prints one JSON object:
+algorithmic bytes of the fp16 / int8 scan (rows*row_bytes + B*row_bytes) / HIP-event kernel time."""
+import sys, json, time, torch
+sys.path.insert(0, '.')
+from rag_application_amd import engine as eng, synth
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+D = 768
+ix = eng.HxIndex(D, (64,))
+ix.synth_fill(N, synth.SEED_CORPUS)
+out = {"rows": N, "dim": D, "peak_gbs": 8000.0, "runs": []}
+for B in (1, 8, 32):
+    Q = eng.synth_queries_dense(D, 0, B, synth.SEED_QUERY)
+    for name, fn, key in (("fp16 scan + exact fp32 re-score, top-10", lambda: ix.search_dense(Q, 10), "scan_f16"),
+                          ("int8 scan (exact), top-10", lambda: ix.search_i8(Q, 10), "scan_i8")):
+        fn(); fn(); torch.cuda.synchronize()
+        ix.profile(True); ix.profile_read()
+        t0 = time.perf_counter()
+        for _ in range(5): fn()
+        torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
+        p = ix.profile_read()[key]; ix.profile(False)
+        gbs = p["bytes"] / p["ms"] / 1e6
+        out["runs"].append({"batch": B, "stage": name, "total_ms": round(ms, 3), "scan_ms": round(p["ms"] / 5, 3),
+                            "scan_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / 8000.0, 3),
+                            "queries_per_s": round(B / ms * 1e3, 1)})
+print(json.dumps(out))
