@@ -39,7 +39,14 @@ class ShardedIndex:
             return keys
         B, L = keys.shape
         out = torch.empty((self.world * B, L), dtype=keys.dtype, device=keys.device)   # rank-major concat
-        dist.all_gather_into_tensor(out, keys.contiguous(), group=self.group)
+        if dist.get_backend(self.group) == "gloo":   # CPU tests / rehearsals: gloo has no flat all-gather on devices
+            parts = list(out.view(self.world, B, L).unbind(0))
+            host = [torch.empty((B, L), dtype=keys.dtype) for _ in parts]
+            dist.all_gather(host, keys.contiguous().cpu(), group=self.group)
+            for p, h in zip(parts, host):
+                p.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, keys.contiguous(), group=self.group)
         return out.view(self.world, B, L).permute(1, 0, 2).reshape(B, -1)
 
     def _global(self, keys, limit, dedupe=False):
