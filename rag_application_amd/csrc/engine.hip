@@ -89,6 +89,8 @@ struct hx_index {
   int64_t sp_docs_built = 0;
   Workspace ws;
   int64_t dense_fallbacks = 0, i8_fallbacks = 0, retries = 0;
+  float q8_rinv_max = 0.f;          // max of q8_rinv[0, q8_rinv_max_rows): the int8 scan's bound
+  int64_t q8_rinv_max_rows = -1;
   int scan_logcap = SCAN8_LOGCAP;   // entries per wave log (HX_DEBUG_SCAN8_LOGCAP shrinks it: tests)
   // optional HIP-event profile of the scan / sparse kernels (hx_profile)
   struct ProfRec { hipEvent_t a, b; int what; double flops, bytes; };
@@ -326,6 +328,16 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   a.id_base = h->id_base;
   a.rinv_x = h->q8_rinv;
   a.rinv_q = rinv_q;
+  if (kind == KIND_I8) {
+    if (h->q8_rinv_max_rows != h->n) {   // rows were added since: one reduction + a 4-byte read-back
+      float* d = (float*)h->ws.get(WS_MISC, 256);
+      launch_max_nonneg(h->q8_rinv, h->n, d, st);
+      HX_HIP(hipMemcpyAsync(&h->q8_rinv_max, d, 4, hipMemcpyDeviceToHost, st));
+      HX_HIP(hipStreamSynchronize(st));
+      h->q8_rinv_max_rows = h->n;
+    }
+    a.rinv_x_max = h->q8_rinv_max;
+  }
   uint4* hitlog = nullptr;
   int* hitcnt = nullptr;
   if (bn == 256) {   // per-wave append logs of the 256 x 256 kernel (scan8.hip)

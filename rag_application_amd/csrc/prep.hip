@@ -5,6 +5,7 @@
 // the COSINE collection), "matryoshka_{64,128,256}" = normalised prefixes of the RAW
 // embedding (:148-150), "quantized" = clip((x*127).astype(int8)) of the RAW embedding
 // (:144-146).  One wave per row; arithmetic = oracle.cosine_preprocess / quantize_i8.
+#include <algorithm>
 #include "hx_common.hpp"
 #include "kernels.hpp"
 
@@ -170,6 +171,30 @@ void launch_prep_queries_i8(const float* q_raw, int q_dim, int B, int Bpad, int 
   if (Bpad <= 0) return;
   hipLaunchKernelGGL(k_prep_queries_i8, dim3((Bpad + 3) / 4), dim3(256), 0, st, q_raw, q_dim, B, Bpad,
                      dpad8, q8, rinv_q);
+  HX_HIP(hipGetLastError());
+}
+
+// max of n non-negative floats -> *out (as its bit pattern, which orders like the value); *out
+// must be zeroed before
+__global__ void k_max_nonneg(const float* p, int64_t n, unsigned int* out) {
+  unsigned int m = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = p[i];
+    const unsigned int b = v > 0.f ? __float_as_uint(v) : 0u;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned int o = __shfl_down(m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+void launch_max_nonneg(const float* p, int64_t n, float* out_dev, hipStream_t st) {
+  HX_HIP(hipMemsetAsync(out_dev, 0, 4, st));
+  if (n <= 0) return;
+  const int64_t blocks = std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_max_nonneg, dim3((unsigned)blocks), dim3(256), 0, st, p, n, (unsigned int*)out_dev);
   HX_HIP(hipGetLastError());
 }
 

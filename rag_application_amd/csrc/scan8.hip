@@ -233,51 +233,55 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     //   TS = 32: rows 8*(e>>2) + 4*hh + (e&3);  TS = 16: rows 4*hh + e   (4 consecutive per group)
     const int q0 = qt * 256 + wn * 64 + hb * 32 + r;
     const int64_t rowq = a.row_begin + (int64_t)rt * 256 + wm * 128 + ha * 64 + 4 * hh;
+    // (plain fmaxf / max chains: hipcc forms v_max3 itself, and -- unlike an inline-asm v_max3 --
+    // gets the MFMA-result wait states its hazard recognizer inserts for instructions it knows)
     auto max3 = [](float x, float y, float z) __attribute__((always_inline)) {
-      float o;
-      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z));
-      return o;
+      return __builtin_fmaxf(__builtin_fmaxf(x, y), z);
     };
+    auto imax3 = [](int x, int y, int z) __attribute__((always_inline)) {
+      const int t = x > y ? x : y;
+      return t > z ? t : z;
+    };
+    (void)max3;
+    (void)imax3;
     constexpr int NG = EPT / 4;   // groups of 4 consecutive rows per tile
-    float tau[NT], sc[NT][MT][EPT], gm[NT][MT][NG], m[NT];
+    // m[nt] >= (an upper bound of) the best score of the lane's column of tile nt
+    float tau[NT], m[NT];
     bool any = false;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       tau[nt] = lds_tau[q0 + nt * TS];
-      float rq = 0.f;
-      if constexpr (KIND == KIND_I8) rq = lds_rq[q0 + nt * TS];
+      if constexpr (KIND == KIND_F16) {
+        // (v_max3_f32 returns the maximum of the non-NaN operands; garbage rows past the end of
+        // the matrix may hold NaNs and are dropped by the row < row_end test anyway)
+        float mm = c[0][nt][0];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          if constexpr (KIND == KIND_F16) {
+          for (int g = 0; g < NG; ++g)
+            mm = max3(max3(mm, c[mt][nt][4 * g], c[mt][nt][4 * g + 1]), c[mt][nt][4 * g + 2], c[mt][nt][4 * g + 3]);
+        m[nt] = mm;
+      } else {
+        // int8: score = (f32(dot) * rinv_x[row]) * rinv_q[q], all factors >= 0 for dot > 0 and
+        // rounding is monotone, so (f32(max dot) * max rinv_x) * rinv_q bounds the column from
+        // above without touching the per-row scales (a VGPR-destination load here would make
+        // hipcc drain the LDS-DMA queue); k_scatter_log computes the exact scores.
+        int im = c[0][nt][0];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sc[nt][mt][4 * g + i] = c[mt][nt][4 * g + i];
-          } else {
-            const f32x4 rx = *(const GF4*)(g_rinv_x + rowq + mt * TS + 8 * g);   // padded past n_rows
-            sc[nt][mt][4 * g + 0] = ((float)c[mt][nt][4 * g + 0] * rx.x) * rq;
-            sc[nt][mt][4 * g + 1] = ((float)c[mt][nt][4 * g + 1] * rx.y) * rq;
-            sc[nt][mt][4 * g + 2] = ((float)c[mt][nt][4 * g + 2] * rx.z) * rq;
-            sc[nt][mt][4 * g + 3] = ((float)c[mt][nt][4 * g + 3] * rx.w) * rq;
-          }
-          // (v_max3_f32 returns the maximum of the non-NaN operands; garbage rows past the end
-          // of the matrix may hold NaNs and are dropped by the row < row_end test anyway)
-          gm[nt][mt][g] = max3(max3(sc[nt][mt][4 * g], sc[nt][mt][4 * g + 1], sc[nt][mt][4 * g + 2]),
-                               sc[nt][mt][4 * g + 3], sc[nt][mt][4 * g + 3]);
-        }
-      float mm = gm[nt][0][0];
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) mm = max3(mm, gm[nt][mt][g], gm[nt][mt][g]);
-      m[nt] = mm;
-      any |= (mm >= tau[nt]);
+          for (int g = 0; g < NG; ++g)
+            im = imax3(imax3(im, c[mt][nt][4 * g], c[mt][nt][4 * g + 1]), c[mt][nt][4 * g + 2], c[mt][nt][4 * g + 3]);
+        m[nt] = im > 0 ? ((float)im * a.rinv_x_max) * lds_rq[q0 + nt * TS] : 0.f;
+      }
+      any |= (m[nt] >= tau[nt]);
     }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) == 0ull, 1)) return;
     // Rare path, kept SHORT (it is inlined in every phase of every k-tile body, and a long one
     // pushed the kernel far past the instruction cache): a lane whose column reached its
-    // threshold logs the whole column -- {query, first row} + its MT x EPT scores -- with plain
-    // stores; k_scatter_log picks the passing rows.
+    // threshold (bound) logs the whole column -- {query, first row} + its MT x EPT accumulators
+    // (fp16: the scores; int8: the integer dots) -- with plain stores; k_scatter_log picks the
+    // passing rows.
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const bool hit = m[nt] >= tau[nt];
@@ -293,11 +297,14 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
-              e[1 + mt * NG + g] = u32x4{__builtin_bit_cast(uint32_t, sc[nt][mt][4 * g + 0]),
-                                         __builtin_bit_cast(uint32_t, sc[nt][mt][4 * g + 1]),
-                                         __builtin_bit_cast(uint32_t, sc[nt][mt][4 * g + 2]),
-                                         __builtin_bit_cast(uint32_t, sc[nt][mt][4 * g + 3])};
+            for (int g = 0; g < NG; ++g) {
+              // (element copies first: __builtin_bit_cast applied directly to an ext-vector element
+              // reference yields element 0 -- hipcc, ROCm 7.2)
+              const auto x0 = c[mt][nt][4 * g + 0], x1 = c[mt][nt][4 * g + 1], x2 = c[mt][nt][4 * g + 2],
+                         x3 = c[mt][nt][4 * g + 3];
+              e[1 + mt * NG + g] = u32x4{__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, x1),
+                                         __builtin_bit_cast(uint32_t, x2), __builtin_bit_cast(uint32_t, x3)};
+            }
         } else {
           g_ovf[q] = 1;
         }
@@ -492,44 +499,84 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 #undef S8_WAIT
 }
 
-// one workgroup per wave log: every entry is a lane's column of one quadrant (see the filter);
-// rows whose score reaches the query's threshold go to the per-query candidate buffers (order is
-// irrelevant, k_compact sorts them).  tau is what the scan used: nothing updates it in between.
-template <int TS>
-__global__ __launch_bounds__(256) void k_scatter_log(const uint4* __restrict__ log, const int* __restrict__ hitcnt,
-                                                     int logcap, const float* __restrict__ tau, int64_t row_end,
-                                                     int64_t id_base, uint64_t* __restrict__ cand,
-                                                     int* __restrict__ cnt, int* __restrict__ ovf, int cap) {
+// Logs -> per-query candidate buffers.  Every entry is a lane's column of one quadrant (see the
+// filter); rows whose score reaches the query's threshold are appended (order is irrelevant,
+// k_compact sorts).  tau is what the scan used: nothing updates it in between.
+//
+// Device-scope atomics run at the memory side (the XCDs' L2s are not coherent): one returning
+// atomic per candidate made this kernel take 0.25-0.5 ms whatever the launch (2M scattered atomics).
+// A workgroup therefore takes the logs of S8_SB scan workgroups x the two waves that share a query
+// column group (wave & 3), i.e. at most 64 * nq_tiles distinct queries: pass 1 counts per query in
+// LDS, ONE global atomic per (workgroup, query) reserves a range, pass 2 re-reads the logs and
+// places the keys with LDS atomics.
+constexpr int S8_SB = 8;
+template <int KIND, int TS>
+__global__ __launch_bounds__(1024) void k_scatter_log(const uint4* __restrict__ log, const int* __restrict__ hitcnt,
+                                                      int logcap, int n_scan_blocks, int nq_tiles,
+                                                      const float* __restrict__ tau, int64_t row_end, int64_t id_base,
+                                                      const float* __restrict__ rinv_x, const float* __restrict__ rinv_q,
+                                                      uint64_t* __restrict__ cand, int* __restrict__ cnt,
+                                                      int* __restrict__ ovf, int cap) {
   constexpr int MT = 64 / TS, EPT = TS * TS / 64, NG = EPT / 4, ENTRY = 1 + MT * NG;
-  const int w = blockIdx.x;
-  int n = hitcnt[w];
-  n = n < logcap ? n : logcap;
-  const uint4* base = log + (int64_t)w * logcap * ENTRY;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const uint4* e = base + (int64_t)i * ENTRY;
-    const uint4 h = e[0];
-    const int q = (int)h.x;
-    const int64_t row0 = (int64_t)(((uint64_t)h.z << 32) | h.y);
-    const float t = tau[q];
+  __shared__ int lcnt[S8_MAXQ / 4];    // per query of the column group: candidates, then next slot
+  const int tid = threadIdx.x;
+  const int wn = blockIdx.x & 3;                      // query column group
+  const int sb0 = (blockIdx.x >> 2) * S8_SB;          // first scan workgroup
+  const int nloc = nq_tiles * 64;                     // queries of the group: q = qt*256 + wn*64 + j
+  for (int i = tid; i < nloc; i += 1024) lcnt[i] = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int l = 0; l < 2 * S8_SB; ++l) {
+      const int sb = sb0 + (l >> 1);
+      if (sb >= n_scan_blocks) break;
+      const int w = sb * 8 + (l & 1) * 4 + wn;        // waves wn and wn + 4 of the scan workgroup
+      int n = hitcnt[w];
+      n = n < logcap ? n : logcap;
+      const uint4* base = log + (int64_t)w * logcap * ENTRY;
+      for (int i = tid; i < n; i += 1024) {
+        const uint4* e = base + (int64_t)i * ENTRY;
+        const uint4 h = e[0];
+        const int q = (int)h.x;
+        const int loc = (q >> 8) * 64 + (q & 63);
+        const int64_t row0 = (int64_t)(((uint64_t)h.z << 32) | h.y);
+        const float t = tau[q];
+        float rq = 0.f;
+        if constexpr (KIND == KIND_I8) rq = rinv_q[q];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const uint4 v = e[1 + mt * NG + g];
-        const uint32_t bits[4] = {v.x, v.y, v.z, v.w};
+          for (int g = 0; g < NG; ++g) {
+            const uint4 v = e[1 + mt * NG + g];
+            const uint32_t bits[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float s = __builtin_bit_cast(float, bits[k]);
-          const int64_t row = row0 + mt * TS + 8 * g + k;
-          if (s >= t && row < row_end) {
-            const int pos = atomicAdd(cnt + q, 1);
-            if (pos < cap)
-              cand[(int64_t)q * cap + pos] = make_key(s, (uint32_t)(id_base + row));
-            else
-              ovf[q] = 1;
+            for (int k = 0; k < 4; ++k) {
+              const int64_t row = row0 + mt * TS + 8 * g + k;
+              if (row >= row_end) continue;
+              float s;
+              if constexpr (KIND == KIND_F16) s = __builtin_bit_cast(float, bits[k]);
+              else s = __fmul_rn(__fmul_rn((float)(int)bits[k], rinv_x[row]), rq);   // the oracle's int8 score
+              if (s >= t) {
+                const int pos = atomicAdd(&lcnt[loc], 1);   // pass 0: count; pass 1: global slot
+                if (pass == 1) {
+                  if (pos < cap)
+                    cand[(int64_t)q * cap + pos] = make_key(s, (uint32_t)(id_base + row));
+                  else
+                    ovf[q] = 1;
+                }
+              }
+            }
           }
-        }
       }
+    }
+    __syncthreads();
+    if (pass == 0) {
+      for (int i = tid; i < nloc; i += 1024) {
+        const int c = lcnt[i];
+        const int q = (i >> 6) * 256 + wn * 64 + (i & 63);
+        lcnt[i] = c > 0 ? atomicAdd(cnt + q, c) : 0;   // first slot of this workgroup's range
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -559,8 +606,15 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st) {
   else
     hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
   HX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_scatter_log<HX_S8_TS>, dim3((unsigned)g * 8), dim3(256), 0, st, a.hitlog, a.hitcnt, a.logcap,
-                     a.tau, a.row_end, a.id_base, a.cand, a.cnt, a.overflow, a.cap);
+  const unsigned sg = (unsigned)((g + S8_SB - 1) / S8_SB) * 4;
+  if (kind == KIND_F16)
+    hipLaunchKernelGGL((k_scatter_log<KIND_F16, HX_S8_TS>), dim3(sg), dim3(1024), 0, st, a.hitlog, a.hitcnt, a.logcap,
+                       (int)g, a.nq_tiles, a.tau, a.row_end, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt, a.overflow,
+                       a.cap);
+  else
+    hipLaunchKernelGGL((k_scatter_log<KIND_I8, HX_S8_TS>), dim3(sg), dim3(1024), 0, st, a.hitlog, a.hitcnt, a.logcap,
+                       (int)g, a.nq_tiles, a.tau, a.row_end, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt, a.overflow,
+                       a.cap);
   HX_HIP(hipGetLastError());
 }
 
