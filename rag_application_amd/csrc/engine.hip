@@ -89,8 +89,8 @@ struct hx_index {
   int64_t sp_docs_built = 0;
   Workspace ws;
   int64_t dense_fallbacks = 0, i8_fallbacks = 0, retries = 0;
-  float q8_rinv_max = 0.f;          // max of q8_rinv[0, q8_rinv_max_rows): the int8 scan's bound
-  int64_t q8_rinv_max_rows = -1;
+  float* q8_tile_max = nullptr;     // max of q8_rinv per 256-row tile: the int8 scan's column bound
+  int64_t q8_tile_max_rows = -1, q8_tile_max_cap = 0;
   int scan_logcap = SCAN8_LOGCAP;   // entries per wave log (HX_DEBUG_SCAN8_LOGCAP shrinks it: tests)
   // optional HIP-event profile of the scan / sparse kernels (hx_profile)
   struct ProfRec { hipEvent_t a, b; int what; double flops, bytes; };
@@ -329,14 +329,17 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   a.rinv_x = h->q8_rinv;
   a.rinv_q = rinv_q;
   if (kind == KIND_I8) {
-    if (h->q8_rinv_max_rows != h->n) {   // rows were added since: one reduction + a 4-byte read-back
-      float* d = (float*)h->ws.get(WS_MISC, 256);
-      launch_max_nonneg(h->q8_rinv, h->n, d, st);
-      HX_HIP(hipMemcpyAsync(&h->q8_rinv_max, d, 4, hipMemcpyDeviceToHost, st));
-      HX_HIP(hipStreamSynchronize(st));
-      h->q8_rinv_max_rows = h->n;
+    if (h->q8_tile_max_rows != h->n) {   // rows were added since the last int8 scan
+      const int64_t tiles = (h->cap + 255) / 256;
+      if (tiles > h->q8_tile_max_cap) {
+        if (h->q8_tile_max) HX_HIP(hipFree(h->q8_tile_max));
+        HX_HIP(hipMalloc((void**)&h->q8_tile_max, (size_t)tiles * 4));
+        h->q8_tile_max_cap = tiles;
+      }
+      launch_tile_max(h->q8_rinv, h->n, h->q8_tile_max, st);
+      h->q8_tile_max_rows = h->n;
     }
-    a.rinv_x_max = h->q8_rinv_max;
+    a.rinv_tile_max = h->q8_tile_max;
   }
   uint4* hitlog = nullptr;
   int* hitcnt = nullptr;
@@ -785,6 +788,7 @@ int hx_destroy(hx_index* h) {
   h->set_device();
   (void)hipDeviceSynchronize();
   free_sparse_index(h);
+  if (h->q8_tile_max) (void)hipFree(h->q8_tile_max);
   void* ptrs[] = {h->dense, h->dense_h, h->q8, h->q8_rinv, h->pre[0], h->pre[1], h->pre[2], h->pre_h0,
                   h->sp_indptr, h->sp_idx, h->sp_val, h->sp_counter};
   for (void* p : ptrs)

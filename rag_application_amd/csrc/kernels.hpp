@@ -29,7 +29,7 @@ struct ScanArgs {
   int64_t id_base;
   const float* rinv_x;     // i8: 1/||x|| per local row (padded)
   const float* rinv_q;     // i8: 1/||q|| per query (padded)
-  float rinv_x_max;        // i8, scan8: an upper bound of rinv_x over the scanned rows
+  const float* rinv_tile_max;  // i8, scan8: max of rinv_x over every 256-row tile (index: local row / 256)
   // scan8 only: per-wave append logs.  A passing (key, query) is stored -- fire and forget -- at
   // hitlog[wave * logcap + i]; launch_scatter_log moves the logs into cand/cnt afterwards.
   // hitlog == NULL (or a launch expected to pass most rows) selects the atomic-append kernel.
@@ -126,8 +126,8 @@ struct PrepRowsArgs {
   _Float16* pre_h0;        // fp16 copy of prefix 0 (may be NULL)
 };
 void launch_prep_rows(const PrepRowsArgs& a, hipStream_t st);
-// *out_dev = max of n non-negative floats (0 for n = 0)
-void launch_max_nonneg(const float* p, int64_t n, float* out_dev, hipStream_t st);
+// out[t] = max of the non-negative floats p[256 t, 256 t + 256) (clipped to n)
+void launch_tile_max(const float* p, int64_t n, float* out, hipStream_t st);
 void launch_synth_dense(float* raw, int64_t row0_global, int64_t n, int dim, uint32_t seed, hipStream_t st);
 
 // Prepare a query batch for one named vector: normalised fp32 [B x dpad] (+ fp16

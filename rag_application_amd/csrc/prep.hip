@@ -174,27 +174,29 @@ void launch_prep_queries_i8(const float* q_raw, int q_dim, int B, int Bpad, int 
   HX_HIP(hipGetLastError());
 }
 
-// max of n non-negative floats -> *out (as its bit pattern, which orders like the value); *out
-// must be zeroed before
-__global__ void k_max_nonneg(const float* p, int64_t n, unsigned int* out) {
-  unsigned int m = 0u;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float v = p[i];
-    const unsigned int b = v > 0.f ? __float_as_uint(v) : 0u;
-    m = b > m ? b : m;
+// out[t] = max of the non-negative floats p[256 t .. 256 t + 255] (clipped to n): one wave per tile
+__global__ __launch_bounds__(256) void k_tile_max(const float* p, int64_t n, float* out) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t * 256 >= n) return;
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = t * 256 + k * 64 + lane;
+    const float v = i < n ? p[i] : 0.f;
+    m = v > m ? v : m;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned int o = __shfl_down(m, off, 64);
+    const float o = __shfl_down(m, off, 64);
     m = o > m ? o : m;
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  if (lane == 0) out[t] = m;
 }
-void launch_max_nonneg(const float* p, int64_t n, float* out_dev, hipStream_t st) {
-  HX_HIP(hipMemsetAsync(out_dev, 0, 4, st));
+void launch_tile_max(const float* p, int64_t n, float* out, hipStream_t st) {
   if (n <= 0) return;
-  const int64_t blocks = std::min<int64_t>((n + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_max_nonneg, dim3((unsigned)blocks), dim3(256), 0, st, p, n, (unsigned int*)out_dev);
+  const int64_t tiles = (n + 255) / 256;
+  hipLaunchKernelGGL(k_tile_max, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p, n, out);
   HX_HIP(hipGetLastError());
 }
 

@@ -247,6 +247,12 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     constexpr int NG = EPT / 4;   // groups of 4 consecutive rows per tile
     // m[nt] >= (an upper bound of) the best score of the lane's column of tile nt
     float tau[NT], m[NT];
+    float rxm = 0.f;   // int8: max row scale of this 256-row tile (a scalar load: lgkmcnt, not vmcnt)
+    if constexpr (KIND == KIND_I8) {
+      // constant address space + uniform index = s_load_dword
+      typedef __attribute__((address_space(4))) const float CF;
+      rxm = ((CF*)a.rinv_tile_max)[(a.row_begin >> 8) + rt];
+    }
     bool any = false;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -263,8 +269,8 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
         m[nt] = mm;
       } else {
         // int8: score = (f32(dot) * rinv_x[row]) * rinv_q[q], all factors >= 0 for dot > 0 and
-        // rounding is monotone, so (f32(max dot) * max rinv_x) * rinv_q bounds the column from
-        // above without touching the per-row scales (a VGPR-destination load here would make
+        // rounding is monotone, so (f32(max dot) * max rinv_x of the tile) * rinv_q bounds the
+        // column from above without touching the per-row scales (a VGPR-destination load here would make
         // hipcc drain the LDS-DMA queue); k_scatter_log computes the exact scores.
         int im = c[0][nt][0];
 #pragma unroll
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 #pragma unroll
           for (int g = 0; g < NG; ++g)
             im = imax3(imax3(im, c[mt][nt][4 * g], c[mt][nt][4 * g + 1]), c[mt][nt][4 * g + 2], c[mt][nt][4 * g + 3]);
-        m[nt] = im > 0 ? ((float)im * a.rinv_x_max) * lds_rq[q0 + nt * TS] : 0.f;
+        m[nt] = im > 0 ? ((float)im * rxm) * lds_rq[q0 + nt * TS] : 0.f;
       }
       any |= (m[nt] >= tau[nt]);
     }
