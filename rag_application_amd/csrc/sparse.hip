@@ -61,7 +61,10 @@ __device__ unsigned long long g_sp_stamps[2 * 8 * 4096];
 constexpr int SP_THREADS = HX_SP_THREADS;
 constexpr int SP_WAVES = SP_THREADS / 64;
 constexpr int SP_TG = 16;            // query terms per group (one 16-lane DPP row)
-constexpr int SP_K = 2;              // pipelined path: chunks per wave held in registers per segment
+#ifndef HX_SP_K
+#define HX_SP_K 2
+#endif
+constexpr int SP_K = HX_SP_K;        // pipelined path: chunks per wave held in registers per segment
 constexpr int SP_TCH = 64;           // k_sparse_order: term-count buckets
 constexpr int SP_TCACHE = 256;       // query terms whose table row is resolved once per workgroup
 constexpr double SP_FIX = 1099511627776.0;          // 2^40
@@ -312,24 +315,26 @@ struct SpStage {
 constexpr int SP_D = 3;                         // visits a load is in flight
 constexpr int SP_LPV = SP_K + 2;                // asm loads per visit per wave: 2 offsets + SP_K postings
 // The loads in flight live in VGPRs hipcc does not allocate: the kernel is built with
-// amdgpu_num_vgpr(SP_NVGPR) and stage j owns v[SP_NVGPR + 6j .. +5] -- named only inside asm
+// amdgpu_num_vgpr(SP_NVGPR) and stage j owns the next 2*SP_K + 2 registers -- named only inside asm
 // strings (and their clobber lists, so the kernel's register count covers them).  hipcc
 // cannot see a pending value, so it cannot copy one before it has landed (it did: the
 // loop-carried copies it inserted for asm OUTPUT operands read registers ahead of the wait).
 // sp_stage_issue: table offsets first, then the postings -- SP_LPV loads in a fixed order.
 // sp_stage_collect: one counted wait (everything but the SP_D - 1 younger visits' loads has
 // landed), then the values move to ordinary registers.
+static_assert(SP_D == 3, "register map below");
+#if HX_SP_K == 2
+// default: 2 chunk slots per wave, 4 waves per SIMD (two 512-thread workgroups of 64 KiB per CU)
 #define SP_NVGPR 104
-static_assert(SP_K == 2 && SP_D == 3, "register map below");
+#define SP_WPE 4
 #define SP_STAGE_FUNCS(J, R0, R1, R2, R3, R4, R5)                                                          \
-  __device__ __forceinline__ void sp_stage_issue##J(const uint32_t* pl, const uint32_t* ph, const uint2* p0, \
-                                                    const uint2* p1) {                                     \
+  __device__ __forceinline__ void sp_stage_issue##J(const uint32_t* pl, const uint32_t* ph, const uint2* const* pp) { \
     asm volatile("global_load_dword v" #R4 ", %0, off\n\t"                                                 \
                  "global_load_dword v" #R5 ", %1, off\n\t"                                                 \
                  "global_load_dwordx2 v[" #R0 ":" #R1 "], %2, off\n\t"                                     \
                  "global_load_dwordx2 v[" #R2 ":" #R3 "], %3, off"                                         \
                  :                                                                                         \
-                 : "v"(pl), "v"(ph), "v"(p0), "v"(p1)                                                      \
+                 : "v"(pl), "v"(ph), "v"(pp[0]), "v"(pp[1])                                                \
                  : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3, "v" #R4, "v" #R5);                        \
   }                                                                                                        \
   __device__ __forceinline__ void sp_stage_collect##J(uint32_t (&doc)[SP_K], float (&w)[SP_K], uint32_t& o_lo, \
@@ -345,6 +350,35 @@ SP_STAGE_FUNCS(0, 104, 105, 106, 107, 108, 109)
 SP_STAGE_FUNCS(1, 110, 111, 112, 113, 114, 115)
 SP_STAGE_FUNCS(2, 116, 117, 118, 119, 120, 121)
 #undef SP_STAGE_FUNCS
+#else
+// experiment: 1 chunk slot per wave, 6 waves per SIMD (three 512-thread workgroups; needs
+// HX_SEG_DOCS = 4096 so that three accumulators fit the LDS)
+static_assert(HX_SP_K == 1, "HX_SP_K is 1 or 2");
+#define SP_NVGPR 68
+#define SP_WPE 6
+#define SP_STAGE_FUNCS(J, R0, R1, R4, R5)                                                                  \
+  __device__ __forceinline__ void sp_stage_issue##J(const uint32_t* pl, const uint32_t* ph, const uint2* const* pp) { \
+    asm volatile("global_load_dword v" #R4 ", %0, off\n\t"                                                 \
+                 "global_load_dword v" #R5 ", %1, off\n\t"                                                 \
+                 "global_load_dwordx2 v[" #R0 ":" #R1 "], %2, off"                                         \
+                 :                                                                                         \
+                 : "v"(pl), "v"(ph), "v"(pp[0])                                                            \
+                 : "memory", "v" #R0, "v" #R1, "v" #R4, "v" #R5);                                          \
+  }                                                                                                        \
+  __device__ __forceinline__ void sp_stage_collect##J(uint32_t (&doc)[SP_K], float (&w)[SP_K], uint32_t& o_lo, \
+                                                      uint32_t& o_hi) {                                    \
+    asm volatile("s_waitcnt vmcnt(%4)\n\t"                                                                 \
+                 "v_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 "\n\tv_mov_b32 %2, v" #R4 "\n\t"          \
+                 "v_mov_b32 %3, v" #R5                                                                     \
+                 : "=v"(doc[0]), "=v"(w[0]), "=v"(o_lo), "=v"(o_hi)                                        \
+                 : "n"(SP_LPV * (SP_D - 1))                                                                \
+                 : "memory");                                                                              \
+  }
+SP_STAGE_FUNCS(0, 68, 69, 70, 71)
+SP_STAGE_FUNCS(1, 72, 73, 74, 75)
+SP_STAGE_FUNCS(2, 76, 77, 78, 79)
+#undef SP_STAGE_FUNCS
+#endif
 
 __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t* cand, unsigned long long* park, int q,
                                              int part, int s0, int s1, int64_t qb, int T, int tid) {
@@ -382,9 +416,9 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
     }
     const uint32_t* pl = row + clampi(sx + SP_D);
     const uint32_t* ph = row + clampi(sx + SP_D + 1);
-    if constexpr (J == 0) sp_stage_issue0(pl, ph, pp[0], pp[1]);
-    if constexpr (J == 1) sp_stage_issue1(pl, ph, pp[0], pp[1]);
-    if constexpr (J == 2) sp_stage_issue2(pl, ph, pp[0], pp[1]);
+    if constexpr (J == 0) sp_stage_issue0(pl, ph, pp);
+    if constexpr (J == 1) sp_stage_issue1(pl, ph, pp);
+    if constexpr (J == 2) sp_stage_issue2(pl, ph, pp);
   };
   using J0 = std::integral_constant<int, 0>;
   using J1 = std::integral_constant<int, 1>;
@@ -492,7 +526,7 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
 // ---------------------------------------------------------------------------------
 // kernel: pipelined body for queries of up to 16 terms, grouped loop otherwise
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(SP_THREADS, 4) __attribute__((amdgpu_num_vgpr(SP_NVGPR))) void k_sparse_score(SparseQueryArgs a) {
+__global__ __launch_bounds__(SP_THREADS, SP_WPE) __attribute__((amdgpu_num_vgpr(SP_NVGPR))) void k_sparse_score(SparseQueryArgs a) {
   const int tid = threadIdx.x;
   const int slot = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
   const int q = a.q_order ? a.q_order[slot] : slot;     // heaviest queries first
