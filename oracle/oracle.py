@@ -467,3 +467,40 @@ def synth_sparse_queries(seed: int, q0: int, n: int, tables=None):
         val.append(bm25_weight(tf, T)[o])
         indptr.append(indptr[-1] + len(r))
     return (np.asarray(indptr, dtype=np.int64), np.concatenate(idx), np.concatenate(val))
+
+
+# ---- IndexerAPI search_across_spaces ------------------------------------------------
+# IndexerAPI/src/core/storage/neo4j_handler.py:809-1047.  Assumed upstream behaviour, unverifiable
+# offline: a cosine vector index scores (1 + cos) / 2 and the top-k is exact.
+SCOUT_SPACES = ("page", "entity", "column", "relationship")
+SCOUT_SCORE_AFFINE = True      # switch: Neo4j's (1 + cos) / 2; False = raw cosine
+
+
+def scout_score(cos: np.ndarray) -> np.ndarray:
+    cos = np.asarray(cos, F32)
+    if not SCOUT_SCORE_AFFINE:
+        return cos
+    return ((F32(1.0) + cos) * F32(0.5)).astype(F32)
+
+
+def scout_search(spaces: dict, q_raw: np.ndarray, top_k: int, user_id: str, org_id: str):
+    """spaces: name -> (X raw [n, d], user_ids, org_ids).  Returns [(space, row, score)] as
+    neo4j_handler.py:809-827: per space exact cosine top-k (score desc, row asc), tenant filter AFTER
+    the top-k, concatenation in SCOUT_SPACES order, stable sort by score descending, [:limit]."""
+    limit = max(1, int(top_k))
+    agg = []
+    for name in SCOUT_SPACES:
+        if name not in spaces or len(spaces[name][1]) == 0:
+            continue
+        X, users, orgs = spaces[name]
+        Xn = cosine_preprocess(np.asarray(X, F32))
+        qn = cosine_preprocess(np.asarray(q_raw, F32)[None, :])[0]
+        sc = spec_dot(Xn, qn)
+        s, i = topk(sc, np.arange(Xn.shape[0], dtype=np.int64), limit)
+        t = scout_score(s)
+        for r in range(len(i)):
+            row = int(i[r])
+            if users[row] == user_id and orgs[row] == org_id:
+                agg.append((name, row, float(t[r])))
+    agg.sort(key=lambda it: it[2], reverse=True)
+    return agg[:limit]

@@ -343,12 +343,18 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   }
   uint4* hitlog = nullptr;
   int* hitcnt = nullptr;
+  int logcap = h->scan_logcap;
   if (bn == 256) {   // per-wave append logs of the 256 x 256 kernel (scan8.hip)
-    hitlog = (uint4*)h->ws.get(WS_HITLOG, (size_t)SCAN8_WAVES * SCAN8_LOGCAP * SCAN8_ENTRY * sizeof(uint4));
+    // a wave logs about (appended per query) * B / SCAN8_WAVES entries per launch; a full log only
+    // flags its queries for the retry
+    const double per_query = (g.predictive ? predict_rank(g.Lp, (double)g.grow) : g.Lp) * (g.grow - 1.0);
+    const int want = next_pow2((int)std::min(1e9, 3.0 * per_query * B / SCAN8_WAVES) + 1);
+    logcap = std::min(h->scan_logcap, std::max(256, want));
+    hitlog = (uint4*)h->ws.get(WS_HITLOG, (size_t)SCAN8_WAVES * logcap * SCAN8_ENTRY * sizeof(uint4));
     hitcnt = (int*)h->ws.get(WS_HITCNT, (size_t)SCAN8_WAVES * 4);
   }
   a.hitcnt = hitcnt;
-  a.logcap = h->scan_logcap;
+  a.logcap = logcap;
   int* kept = (int*)h->ws.get(WS_KEPT, (size_t)B * 4);
   HX_HIP(hipMemsetAsync(kept, 0, (size_t)B * 4, st));
   int64_t r0 = 0, r1 = std::min<int64_t>(h->n, g.C);

@@ -41,8 +41,11 @@ struct ScanArgs {
   int all_pass;
 };
 constexpr int SCAN8_WAVES = 256 * 8;   // waves of the largest scan8 grid
-constexpr int SCAN8_LOGCAP = 4096;      // entries per wave (expected: a few hundred per launch)
-constexpr int SCAN8_ENTRY = 9;          // 16-byte words per entry, sized for the larger (32x32) tile shape
+constexpr int SCAN8_LOGCAP = 4096;      // most entries per wave log (expected: a few hundred per launch)
+#ifndef HX_S8_TS
+#define HX_S8_TS 16                     // MFMA tile side of scan8.hip: 16 (16x16x32) or 32 (32x32x16)
+#endif
+constexpr int SCAN8_ENTRY = 1 + (64 / HX_S8_TS) * (HX_S8_TS * HX_S8_TS / 64 / 4);   // 16-byte words per log entry
 void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st);
 // scan8.hip: the 256 x 256 staggered-phase kernel behind launch_scan for large batches
 bool scan8_usable(const ScanArgs& a, int bn);

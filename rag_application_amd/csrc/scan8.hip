@@ -60,9 +60,6 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef HX_S8_PH
 #define HX_S8_PH 2   // phases per k-tile: 4 (one quadrant each) or 2 (two quadrants each)
 #endif
-#ifndef HX_S8_TS
-#define HX_S8_TS 16
-#endif
 constexpr int S8_HT = 16384;       // half-tile bytes
 constexpr int S8_MAXQ = 4096;      // queries whose thresholds fit the LDS table
 

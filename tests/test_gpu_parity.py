@@ -503,3 +503,39 @@ def test_scan8_log_overflow(eng, torch_mod, monkeypatch):
     st = ix.stats()
     assert st["retry_queries"] > 0
     ix.close()
+
+
+# ---- IndexerAPI search_across_spaces on the dense top-k kernels ----------------------
+def test_scout_search_across_spaces(eng, torch_mod):
+    """Four spaces, mixed tenants, ties across spaces: items (space, row) and fp32 score bits equal
+    the oracle's (neo4j_handler.py:809-827 semantics: post-filter after top-k, stable merge)."""
+    from rag_application_amd.scout import ScoutIndex
+    dim = 256
+    rng = np.random.default_rng(3)
+    sizes = {"page": 3000, "entity": 5000, "column": 700, "relationship": 1200}
+    sc = ScoutIndex(dim)
+    spaces = {}
+    shared = O.synth_dense(70, 0, 4, dim)                      # identical rows in every space -> ties
+    for k, (name, n) in enumerate(sizes.items()):
+        X = O.synth_dense(71 + k, 0, n, dim)
+        X[10:14] = shared
+        users = [f"u{int(v)}" for v in rng.integers(0, 3, n)]
+        orgs = [f"o{int(v)}" for v in rng.integers(0, 2, n)]
+        for r in range(10, 14):
+            users[r], orgs[r] = "u1", "o0"
+        spaces[name] = (X, users, orgs)
+        sc.add(name, X, users, orgs, [{"n": int(r)} for r in range(n)])
+    Q = np.concatenate([O.synth_dense(80, 0, 6, dim), shared[:2] * np.float32(3.0)])
+    for top_k in (1, 5, 40):
+        got = sc.search_across_spaces_batch(Q, top_k, "u1", "o0")
+        for b in range(Q.shape[0]):
+            exp = O.scout_search(spaces, Q[b], top_k, "u1", "o0")
+            assert [(g["space"], g["row"]) for g in got[b]] == [(s, r) for s, r, _ in exp], f"scout b={b} k={top_k}"
+            np.testing.assert_array_equal(np.asarray([g["score"] for g in got[b]], np.float32).view(np.uint32),
+                                          np.asarray([t for _, _, t in exp], np.float32).view(np.uint32))
+            assert all(g["n"] == g["row"] for g in got[b])
+    one = sc.search_across_spaces(Q[0], 5, "u1", "o0")
+    assert [(g["space"], g["row"]) for g in one] == [(g["space"], g["row"]) for g in
+                                                      sc.search_across_spaces_batch(Q[:1], 5, "u1", "o0")[0]]
+    assert sc.search_across_spaces(Q[0], 5, "nobody", "o0") == []
+    sc.close()

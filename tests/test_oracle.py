@@ -223,3 +223,34 @@ def test_synth_generators_agree(synth_tables):
     np.testing.assert_array_equal(bits(sv), bits(csv))
     assert (synth.SEED_CORPUS, synth.SEED_QUERY, synth.SEED_SPDOC, synth.SEED_SPQUERY) == \
         (O.SEED_CORPUS, O.SEED_QUERY, O.SEED_SPDOC, O.SEED_SPQUERY)
+
+
+# ---- IndexerAPI search_across_spaces (neo4j_handler.py:809-1047) ------------------------------------
+def test_scout_score_kats():
+    # (1 + cos) / 2: 1 -> 1, 0 -> 0.5, -1 -> 0, exact in fp32
+    np.testing.assert_array_equal(O.scout_score(np.array([1.0, 0.0, -1.0, 0.5], np.float32)),
+                                  np.array([1.0, 0.5, 0.0, 0.75], np.float32))
+
+
+def test_scout_post_filter_and_stable_merge():
+    """The tenant predicate applies AFTER the per-space top-k (a space can return fewer than top_k
+    rows), equal scores keep the order page, entity, column, relationship (list.sort is stable)."""
+    d = 8
+    e = np.eye(d, dtype=np.float32)
+    q = e[0]
+    spaces = {
+        # page: best row belongs to another tenant -> it occupies a top-k slot and is then dropped
+        "page": (np.stack([e[0], e[0] + e[1], e[2]]), ["other", "u", "u"], ["o", "o", "o"]),
+        "entity": (np.stack([e[0] + e[1], e[3]]), ["u", "u"], ["o", "o"]),          # ties with page row 1
+        "column": (np.stack([e[0]]), ["u"], ["o2"]),                               # wrong org
+        "relationship": (np.stack([e[0]]), ["u"], ["o"]),
+    }
+    got = O.scout_search(spaces, q, 2, "u", "o")
+    assert [(s, r) for s, r, _ in got] == [("relationship", 0), ("page", 1)]
+    got3 = O.scout_search(spaces, q, 3, "u", "o")
+    assert [(s, r) for s, r, _ in got3] == [("relationship", 0), ("page", 1), ("entity", 0)]
+    assert got3[1][2] == got3[2][2]
+    # top_k = 1: page's only slot is the other tenant's row -> page contributes nothing
+    got1 = O.scout_search(spaces, q, 1, "u", "o")
+    assert [(s, r) for s, r, _ in got1] == [("relationship", 0)]
+    assert O.scout_search(spaces, q, 0, "u", "o") == got1          # limit = max(1, top_k)
