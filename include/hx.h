@@ -164,7 +164,9 @@ int hx_hybrid_query_dev(hx_index* h, const float* q_dense_dev,
 
 /* ---- introspection (tests, bench) ------------------------------------------ */
 typedef struct hx_stats {
-  int64_t n_rows, nnz, n_segments, n_groups, hash_capacity;
+  int64_t n_rows, nnz, n_segments;
+  int64_t n_groups;       /* live terms of the inverted index */
+  int64_t hash_capacity;  /* entries of its [live term x segment] offset table (field names kept from ABI v1) */
   int64_t bytes_dense_f32, bytes_dense_f16, bytes_i8, bytes_prefix, bytes_sparse;
   int64_t dense_fallback_queries;   /* queries whose certificate failed so far */
   int64_t i8_fallback_queries;
