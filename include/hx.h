@@ -162,6 +162,14 @@ int hx_hybrid_query_dev(hx_index* h, const float* q_dense_dev,
                         const float* q_val_dev, int32_t B, int32_t max_terms, const hx_params* p,
                         uint64_t* keys_dev, int32_t* counts_dev, void* stream);
 
+/* ---- persistence ------------------------------------------------------------
+ * The reference asks Qdrant for on-disk vectors (qdrant_handler.py:47-55, 62: on_disk=True,
+ * memmap_threshold).  hx_save writes the collection to one file (stored vectors as they stand plus
+ * the sparse CSR); hx_load creates a new index from it -- searches return the same lists, bit for
+ * bit; the inverted index is rebuilt on the device. */
+int hx_save(hx_index* h, const char* path);
+int hx_load(const char* path, int32_t device, hx_index** out);
+
 /* ---- introspection (tests, bench) ------------------------------------------ */
 typedef struct hx_stats {
   int64_t n_rows, nnz, n_segments;

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -1168,6 +1169,116 @@ int hx_debug_row(hx_index* h, int32_t which, int64_t row, void* out_host) {
   } else {
     throw Error("bad `which`");
   }
+  HX_CATCH
+}
+
+// ---- persistence -------------------------------------------------
+// The reference asks Qdrant for on-disk storage (qdrant_handler.py:47-55, 62: on_disk=True,
+// memmap_threshold).  A collection is written as one file: header, then the device arrays as they
+// stand (derived vectors are stored, not re-derived: loading reproduces the index bit for bit) and
+// the doc-major sparse CSR; the inverted index is rebuilt on load (K9, ~1.4 s per 10^9 postings).
+namespace {
+struct HxFileHeader {
+  char magic[8];             // "HXIDX\0\0\1"
+  int32_t dim, n_pre, psize[3], reserved;
+  int64_t id_base, n, sp_rows, nnz;
+};
+const char HX_MAGIC[8] = {'H', 'X', 'I', 'D', 'X', 0, 0, 1};
+constexpr size_t HX_IO_CHUNK = (size_t)64 << 20;
+
+struct File {
+  FILE* f;
+  explicit File(const char* path, const char* mode) : f(fopen(path, mode)) {
+    if (!f) throw Error(std::string("cannot open ") + path);
+  }
+  ~File() { if (f) fclose(f); }
+};
+void dev_to_file(FILE* f, const void* dev, size_t bytes, std::vector<char>& buf) {
+  for (size_t o = 0; o < bytes; o += HX_IO_CHUNK) {
+    const size_t m = std::min(HX_IO_CHUNK, bytes - o);
+    HX_HIP(hipMemcpy(buf.data(), (const char*)dev + o, m, hipMemcpyDeviceToHost));
+    HX_CHECK(fwrite(buf.data(), 1, m, f) == m, "short write");
+  }
+}
+void file_to_dev(FILE* f, void* dev, size_t bytes, std::vector<char>& buf) {
+  for (size_t o = 0; o < bytes; o += HX_IO_CHUNK) {
+    const size_t m = std::min(HX_IO_CHUNK, bytes - o);
+    HX_CHECK(fread(buf.data(), 1, m, f) == m, "short read: truncated index file");
+    HX_HIP(hipMemcpy((char*)dev + o, buf.data(), m, hipMemcpyHostToDevice));
+  }
+}
+}  // namespace
+
+int hx_save(hx_index* h, const char* path) {
+  HX_TRY
+  HX_CHECK(h && path, "NULL argument");
+  h->set_device();
+  HX_HIP(hipDeviceSynchronize());
+  File fl(path, "wb");
+  HxFileHeader hd{};
+  memcpy(hd.magic, HX_MAGIC, 8);
+  hd.dim = h->dim;
+  hd.n_pre = h->n_pre;
+  for (int p = 0; p < 3; ++p) hd.psize[p] = h->psize[p];
+  hd.id_base = h->id_base;
+  hd.n = h->n;
+  hd.sp_rows = h->sp_rows;
+  hd.nnz = h->nnz;
+  HX_CHECK(fwrite(&hd, sizeof hd, 1, fl.f) == 1, "short write");
+  std::vector<char> buf(HX_IO_CHUNK);
+  const size_t n = (size_t)h->n;
+  dev_to_file(fl.f, h->dense, n * h->dim_pad * 4, buf);
+  dev_to_file(fl.f, h->dense_h, n * h->dim_pad * 2, buf);
+  dev_to_file(fl.f, h->q8, n * h->dim_pad8, buf);
+  dev_to_file(fl.f, h->q8_rinv, n * 4, buf);
+  for (int p = 0; p < h->n_pre; ++p) dev_to_file(fl.f, h->pre[p], n * h->psize[p] * 4, buf);
+  if (h->n_pre > 0) dev_to_file(fl.f, h->pre_h0, n * h->psize[0] * 2, buf);
+  if (h->sp_rows > 0) {
+    dev_to_file(fl.f, h->sp_indptr, ((size_t)h->sp_rows + 1) * 8, buf);
+    dev_to_file(fl.f, h->sp_idx, (size_t)h->nnz * 4, buf);
+    dev_to_file(fl.f, h->sp_val, (size_t)h->nnz * 4, buf);
+  }
+  HX_CHECK(fflush(fl.f) == 0, "flush failed");
+  HX_CATCH
+}
+
+int hx_load(const char* path, int32_t device, hx_index** out) {
+  HX_TRY
+  HX_CHECK(path && out, "NULL argument");
+  File fl(path, "rb");
+  HxFileHeader hd{};
+  HX_CHECK(fread(&hd, sizeof hd, 1, fl.f) == 1, "short read: not an index file");
+  HX_CHECK(memcmp(hd.magic, HX_MAGIC, 8) == 0, "not an hx index file (bad magic / version)");
+  HX_CHECK(hd.n >= 0 && hd.sp_rows >= 0 && hd.nnz >= 0 && hd.n_pre >= 0 && hd.n_pre <= 3, "corrupt header");
+  hx_index* h = nullptr;
+  const int rc = hx_create(hd.dim, hd.psize, hd.n_pre, device, hd.id_base, &h);
+  if (rc != 0) return rc;
+  try {
+    h->set_device();
+    std::vector<char> buf(HX_IO_CHUNK);
+    const size_t n = (size_t)hd.n;
+    reserve_rows(h, hd.n);
+    file_to_dev(fl.f, h->dense, n * h->dim_pad * 4, buf);
+    file_to_dev(fl.f, h->dense_h, n * h->dim_pad * 2, buf);
+    file_to_dev(fl.f, h->q8, n * h->dim_pad8, buf);
+    file_to_dev(fl.f, h->q8_rinv, n * 4, buf);
+    for (int p = 0; p < h->n_pre; ++p) file_to_dev(fl.f, h->pre[p], n * h->psize[p] * 4, buf);
+    if (h->n_pre > 0) file_to_dev(fl.f, h->pre_h0, n * h->psize[0] * 2, buf);
+    h->n = hd.n;
+    if (hd.sp_rows > 0) {
+      reserve_sparse(h, hd.sp_rows, hd.nnz);
+      file_to_dev(fl.f, h->sp_indptr, ((size_t)hd.sp_rows + 1) * 8, buf);
+      file_to_dev(fl.f, h->sp_idx, (size_t)hd.nnz * 4, buf);
+      file_to_dev(fl.f, h->sp_val, (size_t)hd.nnz * 4, buf);
+      h->sp_rows = hd.sp_rows;
+      h->nnz = hd.nnz;
+      h->sparse_stale = true;
+    }
+  } catch (...) {
+    (void)hx_destroy(h);
+    throw;
+  }
+  *out = h;
   HX_CATCH
 }
 

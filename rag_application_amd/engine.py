@@ -64,6 +64,27 @@ class HxIndex:
                                    C.byref(self._h)))
         self._tdev = torch.device("cuda", self.device)
 
+    # -- persistence (hx.h: hx_save / hx_load) -----------------------------------------
+    def save(self, path: str) -> None:
+        check(_lib.lib().hx_save(self._h, str(path).encode()))
+
+    @classmethod
+    def load(cls, path: str, device: int = 0) -> "HxIndex":
+        """A new index from a file written by save(): same rows, same search results bit for bit."""
+        import struct
+        with open(path, "rb") as f:
+            head = f.read(8 + 6 * 4 + 4 * 8)
+        magic, dim, n_pre, p0, p1, p2, _r, id_base, _n, _sr, _nnz = struct.unpack("<8s6i4q", head)
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        check(_lib.lib().hx_load(str(path).encode(), int(device), C.byref(self._h)))
+        self.dim = int(dim)
+        self.msizes = tuple(int(m) for m in (p0, p1, p2)[:n_pre])
+        self.device = int(device)
+        self.id_base = int(id_base)
+        self._tdev = torch.device("cuda", self.device)
+        return self
+
     # -- lifecycle -------------------------------------------------------------------
     def close(self):
         if self._h:

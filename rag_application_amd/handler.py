@@ -12,7 +12,9 @@ default)."""
 from __future__ import annotations
 
 import asyncio
+import json
 import logging
+import os
 import threading
 import uuid
 from dataclasses import asdict, dataclass, field
@@ -69,16 +71,40 @@ class _Collection:
     def close(self):
         self.index.close()
 
+    # on-disk form (the reference asks Qdrant for on_disk storage, qdrant_handler.py:47-55, 62):
+    # <dir>/<user>.hx = the engine's file, <dir>/<user>.json = point ids + payloads
+    def save(self, base: str):
+        self.index.save(base + ".hx")
+        with open(base + ".json", "w") as f:
+            json.dump({"dim": self.dim, "msizes": list(self.msizes), "sparse_enabled": self.sparse_enabled,
+                       "ids": self.ids, "payloads": self.payloads}, f)
+
+    @classmethod
+    def load(cls, base: str, device: int):
+        with open(base + ".json") as f:
+            meta = json.load(f)
+        self = cls.__new__(cls)
+        self.dim = int(meta["dim"])
+        self.msizes = tuple(meta["msizes"])
+        self.index = _engine.HxIndex.load(base + ".hx", device=device)
+        self.ids = list(meta["ids"])
+        self.payloads = list(meta["payloads"])
+        self.sparse_enabled = bool(meta["sparse_enabled"])
+        return self
+
 
 class QdrantHandler:
     """Handles vector operations for hybrid search with dense and sparse vectors."""
 
-    def __init__(self, reranker=None, device: int = 0):
+    def __init__(self, reranker=None, device: int = 0, persist_dir: Optional[str] = None):
         # The reference loads jinaai/jina-colbert-v2 here (:17-22) and falls back to the
         # un-reranked list whenever reranking raises (:410-412).  `reranker` is any object
         # with rerank_documents(query, documents, max_tokens) -> list of indices.
         self.reranker = reranker
         self.device = device
+        # persist_dir (additive): collections found there are loaded on first use, `save_collection`
+        # writes them back.  None = in-memory only.
+        self.persist_dir = persist_dir
         self._collections: Dict[str, _Collection] = {}
         self._lock = threading.Lock()
 
@@ -108,8 +134,15 @@ class QdrantHandler:
                 old = self._collections.pop(user_id, None)
                 if old is not None:
                     old.close()
-                col = _Collection(int(dense_vector_size), [int(m) for m in matryoshka_sizes], self.device)
-                col.sparse_enabled = bool(sparse_enabled)
+                base = self._base(user_id)
+                if base and not force_recreate and os.path.exists(base + ".hx") and os.path.exists(base + ".json"):
+                    col = _Collection.load(base, self.device)
+                    if col.dim != int(dense_vector_size):
+                        col.close()
+                        raise ValueError("stored collection has another vector size")
+                else:
+                    col = _Collection(int(dense_vector_size), [int(m) for m in matryoshka_sizes], self.device)
+                    col.sparse_enabled = bool(sparse_enabled)
                 self._collections[user_id] = col
             await self._run(make)
             logging.info(f"Created hybrid search collection for user {user_id}")
@@ -119,6 +152,20 @@ class QdrantHandler:
         except Exception as e:
             logging.critical(f"Collection creation failed for user {user_id}: {str(e)}")
             raise
+
+    def _base(self, user_id: str) -> Optional[str]:
+        if not self.persist_dir:
+            return None
+        safe = "".join(ch if ch.isalnum() or ch in "-_." else "_" for ch in str(user_id))
+        return os.path.join(self.persist_dir, safe)
+
+    async def save_collection(self, user_id: str) -> None:
+        """Write the collection to persist_dir (additive; Qdrant persists on its own)."""
+        if not self.persist_dir:
+            raise ValueError("handler was created without persist_dir")
+        col = self._collections[str(user_id)]
+        os.makedirs(self.persist_dir, exist_ok=True)
+        await self._run(col.save, self._base(user_id))
 
     # --------------------------------------------------------------------------- upserts
     async def _store(self, user_id, items, emb_key_payload):

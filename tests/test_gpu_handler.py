@@ -63,3 +63,36 @@ def test_handler_plumbing_and_parity():
     assert [len(b) for b in batch] == [4, 4, 4] and batch[0][0].id == res[0].id
     run(h.delete_collection("u"))
     assert run(h.get_collection_chunk_count("u")) == 0
+
+
+def test_handler_persistence(tmp_path):
+    """persist_dir (additive): save_collection writes <user>.hx + <user>.json, a NEW handler loads the
+    collection on create_collection and answers the same query with the same ids, scores, payloads."""
+    from rag_application_amd import bm25
+    from rag_application_amd.handler import QdrantHandler
+    n, dim = 400, 768
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    chunks = []
+    for r in range(n):
+        text = f"chunk number {r} about retrieval engines and kernels"
+        idx, val = bm25.embed(text)
+        chunks.append({"content": text, "dense_embedding": X[r].tolist(), "sparse_embedding": {"indices": idx, "values": val},
+                       "chunk_metadata": {"document_id": "d", "user_id": "u", "file_name": "f.txt", "mime_type": "text/plain",
+                                          "file_size": 1, "description": "", "file_path": "/x", "context_version": 1,
+                                          "chunk_number": r, "doc_summary": "s"}})
+    params = dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=60, dense_limit=40,
+                  quantized_limit=40, sparse_limit=50, final_limit=30, hnsw_ef=128)
+    qi, qv = bm25.embed("retrieval kernels")
+    q = O.synth_dense(O.SEED_QUERY, 0, 1, dim)[0].tolist()
+    h1 = QdrantHandler(persist_dir=str(tmp_path))
+    run(h1.store_document_vectors(chunks, "user/1"))
+    a = run(h1.hybrid_search("user/1", "q", q, {"indices": qi, "values": qv}, top_k=7, search_params=params))
+    run(h1.save_collection("user/1"))
+    run(h1.delete_collection("user/1"))
+    h2 = QdrantHandler(persist_dir=str(tmp_path))
+    run(h2.create_collection("user/1"))
+    assert run(h2.get_collection_chunk_count("user/1")) == n
+    b = run(h2.hybrid_search("user/1", "q", q, {"indices": qi, "values": qv}, top_k=7, search_params=params))
+    assert [(r.id, r.score, r.payload) for r in a] == [(r.id, r.score, r.payload) for r in b] and len(a) == 7
+    run(h2.create_collection("user/1", force_recreate=True))       # recreate ignores the stored files
+    assert run(h2.get_collection_chunk_count("user/1")) == 0

@@ -539,3 +539,42 @@ def test_scout_search_across_spaces(eng, torch_mod):
                                                       sc.search_across_spaces_batch(Q[:1], 5, "u1", "o0")[0]]
     assert sc.search_across_spaces(Q[0], 5, "nobody", "o0") == []
     sc.close()
+
+
+# ---- persistence (on-disk collections) ---------------------------------------------
+def test_save_load_round_trip(eng, torch_mod, synth_tables, tmp_path):
+    """hx_save / hx_load: the loaded index answers every stage with the same keys, bit for bit, and
+    can keep growing; a truncated file is refused."""
+    n, dim = 9000, 384
+    ora, ix, X = build_pair(eng, n, dim, (64, 128), synth_tables)
+    path = str(tmp_path / "col.hx")
+    ix.save(path)
+    ld = eng.HxIndex.load(path)
+    assert (ld.dim, ld.msizes, ld.count()) == (dim, (64, 128), n)
+    B = 9
+    Q = torch_mod.from_numpy(O.synth_dense(O.SEED_QUERY, 0, B, dim)).cuda()
+    ip, si, sv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    sp = (torch_mod.from_numpy(ip).cuda(), torch_mod.from_numpy(si.astype(np.int32)).cuda(), torch_mod.from_numpy(sv).cuda())
+    for fn in (lambda i: i.search_dense(Q, 20), lambda i: i.search_dense(Q, 30, 64), lambda i: i.search_i8(Q, 20),
+               lambda i: i.search_sparse(*sp, 25)):
+        (k0, c0), (k1, c1) = fn(ix), fn(ld)
+        assert torch_mod.equal(k0, k1) and torch_mod.equal(c0, c1)
+    # the loaded index is a normal index: add rows, compare with the oracle
+    X2 = O.synth_dense(91, 0, 500, dim)
+    ld.add(X2)
+    ora.add(X2)
+    ora.finalize()
+    keys, cnt = ld.search_dense(Q, 10)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        es, ei = ora.search_dense(Q[b].cpu().numpy(), 10)
+        assert_list_equal(s[b], i[b], c[b], es, ei, f"after load+add b={b}")
+    with open(path, "rb") as f:
+        blob = f.read()
+    bad = str(tmp_path / "bad.hx")
+    with open(bad, "wb") as f:
+        f.write(blob[: len(blob) // 2])
+    with pytest.raises(Exception):
+        eng.HxIndex.load(bad)
+    ix.close()
+    ld.close()
