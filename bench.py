@@ -229,9 +229,11 @@ def main():
                       else f"queries/sec, {wl['desc']}",
             "value": B * args.steps / dt, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32 (fp16 MFMA candidate scan, exact fp32 re-score)",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "rows": rows, "dim": dim, "batch": B, "top_k": 10,
+                       "arithmetic": "fp16 MFMA candidate scan + exact fp32 re-score (certified); sparse: exact 2^40 "
+                                     "fixed-point sums",
                        "sharding": f"rows/{world}", "nnz_per_shard": st["nnz"],
                        "exact_fallback_queries": st["dense_fallback_queries"], "build_s": round(t_build, 2)},
             "roofline": roof, "cpu_baseline": cpu,
