@@ -198,6 +198,14 @@ def main():
                     alg_gb_per_launch=sc["bytes"] / sc["launches"] / 1e9,
                     other_bound_frac=(gbs / PEAK_HBM_GBS) if mfma_bound else (tf / PEAK_FP16_TFLOPS),
                     sparse_ms_per_step=prof["sparse"]["ms"] / max(args.steps, 1))
+        sp = prof["sparse"]
+        if sp["launches"] and sp["ms"] > 0:   # second kernel of the step, HBM-bound by construction
+            roof["second_kernel"] = dict(kernel="k_sparse_score", bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS,
+                                         achieved=sp["bytes"] / sp["ms"] / 1e6,
+                                         frac=sp["bytes"] / sp["ms"] / 1e6 / PEAK_HBM_GBS,
+                                         alg_gb_per_launch=sp["bytes"] / sp["launches"] / 1e9,
+                                         avg_launch_ms=sp["ms"] / sp["launches"],
+                                         note="8 B per posting visited; latency-bound today (DESIGN.md)")
 
     # ---- CPU baseline + parity gate on the sample (rank 0, N = 1 only) ---------------------
     cpu = None

@@ -1149,7 +1149,7 @@ int hx_profile_read(hx_index* h, hx_prof* out) {
     unsigned long long np = 0;
     HX_HIP(hipMemcpy(&np, h->sp_counter, 8, hipMemcpyDeviceToHost));
     HX_HIP(hipMemset(h->sp_counter, 0, 8));
-    out->bytes[2] = (double)np * 6.0;   // u16 doc + f32 weight per posting visited
+    out->bytes[2] = (double)np * 8.0;   // {doc in segment, weight}: 8 B per posting visited
   }
   HX_CATCH
 }

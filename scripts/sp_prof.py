@@ -17,4 +17,4 @@ torch.cuda.synchronize()
 p = ix.profile_read()["sparse"]; ix.profile(False)
 st = ix.stats()
 print(f"rows {N} nnz {st['nnz']} B {B} terms/query {len(qix)/B:.2f}: {p['ms']/3:.3f} ms/launch, bytes/launch {p['bytes']/3/1e9:.3f} GB "
-      f"-> {p['bytes']/p['ms']/1e6:.1f} GB/s; postings/query {p['bytes']/3/6/B:.0f}; segments {st['n_segments']}")
+      f"-> {p['bytes']/p['ms']/1e6:.1f} GB/s; postings/query {p['bytes']/3/8/B:.0f}; segments {st['n_segments']}")
