@@ -162,6 +162,16 @@ int hx_hybrid_query_dev(hx_index* h, const float* q_dense_dev,
                         const float* q_val_dev, int32_t B, int32_t max_terms, const hx_params* p,
                         uint64_t* keys_dev, int32_t* counts_dev, void* stream);
 
+/* ---- sparse text provider (host cores) ---------------------------------------
+ * EmbeddingHandler.encode_sparse (app/core/embedding/embedding_handler.py:101-142 -> fastembed
+ * Qdrant/bm25 :41, :123), batched (the reference's TODO :100): n texts -> CSR of (term id, weight)
+ * rows.  texts[i] = lens[i] UTF-8 bytes.  flags[i] = 1 marks a text with non-ASCII bytes: its row
+ * is empty and the caller handles it (rag_application_amd/bm25.py).  cap = capacity of idx/val
+ * (sum of lens[i]/2 + 1 suffices).  threads <= 0: one per core, at most 16. */
+int hx_bm25_embed_batch(const char* const* texts, const int64_t* lens, int64_t n, double k, double b,
+                        double avg_len, int32_t threads, int64_t* indptr, int32_t* idx, double* val,
+                        int64_t cap, int32_t* flags);
+
 /* ---- persistence ------------------------------------------------------------
  * The reference asks Qdrant for on-disk vectors (qdrant_handler.py:47-55, 62: on_disk=True,
  * memmap_threshold).  hx_save writes the collection to one file (stored vectors as they stand plus

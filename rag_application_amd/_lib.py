@@ -68,6 +68,7 @@ _SIGS = {
     "hx_unpack": [C.c_int32, _P, C.c_int64, _P, _P, _P],
     "hx_hybrid_query_host": [_P, _P, _P, _P, _P, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
     "hx_hybrid_query_dev": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
+    "hx_bm25_embed_batch": [_P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int32, _P, _P, _P, C.c_int64, _P],
     "hx_save": [_P, C.c_char_p],
     "hx_load": [C.c_char_p, C.c_int32, C.POINTER(_P)],
     "hx_get_stats": [_P, C.POINTER(HxStats)],

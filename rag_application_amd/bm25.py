@@ -268,5 +268,69 @@ def embed(text: str, k: float = BM25_K, b: float = BM25_B, avg_len: float = BM25
     return idx, [acc[i] for i in idx]
 
 
-def embed_batch(texts: Iterable[str]):
-    return [embed(t) for t in texts]
+def embed_batch_csr(texts: Iterable[str], native: bool = True, threads: int = 0):
+    """Many texts -> one CSR (indptr int64[n+1], idx int32[nnz], val float64[nnz]): what
+    hx_add_sparse takes.  Native (csrc/bm25.cpp, all host cores) for texts of ASCII + typographic
+    punctuation -- identical to embed() -- and embed() for the rest."""
+    import numpy as np
+    texts = list(texts)
+    n = len(texts)
+    lib = None
+    if native and n:
+        try:
+            import ctypes as C
+            from . import _lib
+            lib = _lib.lib()
+        except Exception:
+            lib = None
+    if lib is None:
+        rows = [embed(t) for t in texts]
+        indptr = np.zeros(n + 1, np.int64)
+        indptr[1:] = np.cumsum([len(r[0]) for r in rows])
+        idx = np.fromiter((i for r in rows for i in r[0]), np.int32, int(indptr[-1]))
+        val = np.fromiter((v for r in rows for v in r[1]), np.float64, int(indptr[-1]))
+        return indptr, idx, val
+    raw = [t.encode("utf-8") for t in texts]
+    arr = (C.c_char_p * n)(*raw)
+    lens = np.fromiter((len(r) for r in raw), np.int64, n)
+    cap = int(lens.sum() // 2 + n)
+    indptr = np.zeros(n + 1, np.int64)
+    idx = np.empty(max(cap, 1), np.int32)
+    val = np.empty(max(cap, 1), np.float64)
+    flags = np.zeros(n, np.int32)
+    rc = lib.hx_bm25_embed_batch(C.cast(arr, C.c_void_p), lens.ctypes.data, n, BM25_K, BM25_B, BM25_AVG_LEN, int(threads),
+                                 indptr.ctypes.data, idx.ctypes.data, val.ctypes.data, cap, flags.ctypes.data)
+    if rc != 0:
+        return embed_batch_csr(texts, native=False)
+    nnz = int(indptr[-1])
+    idx, val = idx[:nnz], val[:nnz]
+    slow = np.flatnonzero(flags)
+    if slow.size:                      # splice the Python rows in
+        rows = {int(i): embed(texts[int(i)]) for i in slow}
+        counts = np.diff(indptr)
+        for i, r in rows.items():
+            counts[i] = len(r[0])
+        new_ptr = np.zeros(n + 1, np.int64)
+        new_ptr[1:] = np.cumsum(counts)
+        nidx = np.empty(int(new_ptr[-1]), np.int32)
+        nval = np.empty(int(new_ptr[-1]), np.float64)
+        keep = np.ones(n, bool)
+        keep[slow] = False
+        # native rows keep their order: copy them in one pass, then fill the spliced rows
+        src = np.concatenate([np.arange(indptr[i], indptr[i + 1]) for i in np.flatnonzero(keep)]) if keep.any() else np.zeros(0, np.int64)
+        dst = np.concatenate([np.arange(new_ptr[i], new_ptr[i + 1]) for i in np.flatnonzero(keep)]) if keep.any() else np.zeros(0, np.int64)
+        nidx[dst] = idx[src]
+        nval[dst] = val[src]
+        for i, r in rows.items():
+            nidx[new_ptr[i]:new_ptr[i + 1]] = r[0]
+            nval[new_ptr[i]:new_ptr[i + 1]] = r[1]
+        indptr, idx, val = new_ptr, nidx, nval
+    return indptr, idx, val
+
+
+def embed_batch(texts: Iterable[str], native: bool = True, threads: int = 0):
+    """Many texts at once -> [(indices, values)] exactly as [embed(t) for t in texts]."""
+    texts = list(texts)
+    indptr, idx, val = embed_batch_csr(texts, native=native, threads=threads)
+    il, vl = idx.tolist(), val.tolist()
+    return [(il[indptr[i]:indptr[i + 1]], vl[indptr[i]:indptr[i + 1]]) for i in range(len(texts))]

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libhx.so")
-SOURCES = ["scan.hip", "scan8.hip", "select.hip", "prep.hip", "sparse.hip", "spbuild.hip", "engine.hip"]
+SOURCES = ["scan.hip", "scan8.hip", "select.hip", "prep.hip", "sparse.hip", "spbuild.hip", "engine.hip", "bm25.cpp"]
 HEADERS = ["hx_common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "hx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function"]
@@ -39,7 +39,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), lib: str = LIB
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ_, s.replace(".hip", ".o"))
+        obj = os.path.join(OBJ_, os.path.splitext(s)[0] + ".o")
         if force or _stale(obj, [src] + hdrs):
             jobs.append([hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-c", src, "-o", obj])
 
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), lib: str = LIB
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ_, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ_, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if force or jobs or _stale(lib, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
     return lib

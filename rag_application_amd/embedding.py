@@ -13,6 +13,7 @@ The Redis cache of the reference (:52-69, 1 h TTL) is service glue; an in-proces
 with the same key format stands in."""
 from __future__ import annotations
 
+import asyncio
 import hashlib
 import logging
 from enum import Enum
@@ -123,5 +124,18 @@ class EmbeddingHandler:
             return {"indices": [], "values": []}
 
     async def encode_sparse_batch(self, texts: List[str]):
-        """Additive: the reference's per-chunk TODO (embedding_handler.py:100)."""
-        return [await self.encode_sparse(t) for t in texts]
+        """Additive: the reference's per-chunk TODO (embedding_handler.py:100).  One native call
+        (csrc/bm25.cpp, all host cores) for the texts that are not cached; same vectors as
+        encode_sparse, same failure convention per text."""
+        try:
+            keys = [self._get_cache_key(t, "sparse") for t in texts]
+            todo = [i for i, k in enumerate(keys) if k not in self.cache]
+            if todo:
+                loop = asyncio.get_running_loop()
+                rows = await loop.run_in_executor(None, bm25.embed_batch, [texts[i] for i in todo])
+                for i, (indices, values) in zip(todo, rows):
+                    self.cache[keys[i]] = {"indices": indices, "values": values}
+            return [SparseVector(**self.cache[k]) for k in keys]
+        except Exception as e:
+            self.logger.error(f"Sparse embedding failed: {str(e)}")
+            return [{"indices": [], "values": []} for _ in texts]

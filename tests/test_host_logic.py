@@ -129,3 +129,33 @@ def test_embedding_handler_contract():
     assert Provider.HUGGINGFACE.value == "huggingface" and ModelType.RERANKER.value == "reranker"
     key = h._get_cache_key("abc", "dense")
     assert key.startswith("embedding:dense:Provider.HUGGINGFACE:m:") and len(key.split(":")[-1]) == 64
+
+
+def test_bm25_native_batch_equals_python():
+    """csrc/bm25.cpp (all host cores) against bm25.embed on every text: ASCII, typographic
+    punctuation (handled natively), other Unicode (flagged, Python path), suffix stress, empties."""
+    import random
+    from rag_application_amd import bm25
+    rnd = random.Random(11)
+    vocab = ("retrieval engines running quickly generously communal arsenal skies dying relational conditional "
+             "rationalization hopefulness sensitivities formalize electricity adjustable replacement adoption "
+             "controlled rolling agreed proceeding succeed news bias sky only early cries cried caresses ponies ties "
+             "gaps gas this kiwis yes toy boy happy happily sadly feudally luxuriated plotted hopping hoping").split()
+    sufs = ["ization", "ational", "fulness", "ousness", "tional", "biliti", "lessli", "entli", "ation", "alism", "aliti",
+            "ousli", "iviti", "fulli", "enci", "anci", "abli", "izer", "ator", "alli", "bli", "ogi", "li", "ative", "ical",
+            "ness", "ful", "ement", "ance", "able", "ment", "ent", "ism", "ate", "iti", "ous", "ive", "ize", "ion", "al", "er",
+            "ic", "ing", "ed", "edly", "ingly", "eed", "eedly", "s", "es", "ies", "ied", "sses", "y", "e", "l", "ll"]
+    texts = [" ".join(rnd.choice(vocab) for _ in range(rnd.randint(0, 80))) for _ in range(300)]
+    texts += [t.upper() for t in texts[:20]]
+    texts += [" ".join(s + u for s in ("hop", "relat", "sens", "geolog", "commun", "gener", "fizz", "tray", "cry", "x")
+                       for u in sufs)]
+    texts += ["", "the of and", "_ __ a_b x" * 3, "it's the runners' run; e-mail: a@b.c (ok)", "w" * 41 + " fine",
+              "x—y × z § 8 “quoted” …", "naïve café", "½ cup ²", "тест text",
+              "tabs\tand\nnewlines\r\nmix"]
+    ref = [bm25.embed(t) for t in texts]
+    assert bm25.embed_batch(texts) == ref
+    assert bm25.embed_batch(texts, native=False) == ref
+    ip, ix, v = bm25.embed_batch_csr(texts)
+    assert ip[-1] == sum(len(r[0]) for r in ref) and ix.dtype == np.int32 and v.dtype == np.float64
+    for i, (ri, rv) in enumerate(ref):
+        assert ix[ip[i]:ip[i + 1]].tolist() == ri and v[ip[i]:ip[i + 1]].tolist() == rv
