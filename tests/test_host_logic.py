@@ -159,3 +159,14 @@ def test_bm25_native_batch_equals_python():
     assert ip[-1] == sum(len(r[0]) for r in ref) and ix.dtype == np.int32 and v.dtype == np.float64
     for i, (ri, rv) in enumerate(ref):
         assert ix[ip[i]:ip[i + 1]].tolist() == ri and v[ip[i]:ip[i + 1]].tolist() == rv
+
+
+def test_encode_sparse_batch_matches_single():
+    import asyncio
+    from rag_application_amd.embedding import EmbeddingHandler
+    h = EmbeddingHandler()
+    texts = ["hybrid dense sparse retrieval", "", "Kernels and wavefronts — quickly!", "hybrid dense sparse retrieval"]
+    one = [asyncio.run(h.encode_sparse(t)) for t in texts]
+    h2 = EmbeddingHandler()
+    many = asyncio.run(h2.encode_sparse_batch(texts))
+    assert [(list(a.indices), list(a.values)) for a in one] == [(list(b.indices), list(b.values)) for b in many]
