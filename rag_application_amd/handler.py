@@ -23,6 +23,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 from . import engine as _engine
+from . import filters as _filters
 from ._lib import HX_MODE_TREE
 
 
@@ -251,8 +252,6 @@ class QdrantHandler:
 
     # ---------------------------------------------------------------------------- search
     def _search_sync(self, user_id, dense_vectors, sparse_vectors, search_params, filters):
-        if filters:
-            raise NotImplementedError("payload filters are not supported yet (no reference call site uses them)")
         col = self._collections[str(user_id)]
         q = np.asarray(dense_vectors, dtype=np.float32).reshape(len(sparse_vectors), -1)
         if q.shape[1] != col.dim:
@@ -264,12 +263,22 @@ class QdrantHandler:
             val.extend(float(v) for v in vv)
             indptr.append(len(idx))
         hp = _engine.make_params(search_params, mode=HX_MODE_TREE)   # KeyError/TypeError like the reference
+        final_limit = int(hp.final_limit)
+        if filters:
+            # query_filter belongs to the ROOT query only (:297, :371): the union of the branches'
+            # candidates (<= dense_limit + the fusion's 10) is re-scored, filtered, cut to final_limit.
+            # So: ask the engine for the whole re-scored union and filter it here.
+            _filters.matches({}, filters)                  # validates the clause names before any GPU work
+            hp.final_limit = min(int(hp.dense_limit) + int(hp.rrf_limit), 2048)
         scores, ids, counts = col.index.hybrid_query_host(
             q, np.asarray(indptr, np.int64), np.asarray(idx, np.int32), np.asarray(val, np.float32), hp)
         out = []
         for b in range(q.shape[0]):
-            out.append([ScoredPoint(id=col.ids[int(r)], version=0, score=float(s), payload=col.payloads[int(r)])
-                        for s, r in zip(scores[b, :counts[b]], ids[b, :counts[b]])])
+            pts = [ScoredPoint(id=col.ids[int(r)], version=0, score=float(s), payload=col.payloads[int(r)])
+                   for s, r in zip(scores[b, :counts[b]], ids[b, :counts[b]])]
+            if filters:
+                pts = [p for p in pts if _filters.matches(p.payload, filters, p.id)][:final_limit]
+            out.append(pts)
         return out
 
     async def hybrid_search(self, user_id: str, query_text: str, dense_vector: List[float],
@@ -338,9 +347,11 @@ class QdrantHandler:
             if str(user_id) not in self._collections:
                 logging.warning(f"Collection for user {user_id} does not exist.")
                 return 0
-            if filters:
-                raise NotImplementedError("payload filters are not supported yet")
-            return await self._run(self._collections[str(user_id)].index.count)
+            col = self._collections[str(user_id)]
+            if filters:   # :464-470: count the points the filter keeps
+                return await self._run(lambda: sum(1 for i, p in zip(col.ids, col.payloads)
+                                                   if _filters.matches(p, filters, i)))
+            return await self._run(col.index.count)
         except Exception as e:
             logging.error(f"Failed to get chunk count for user {user_id}: {str(e)}")
             return 0

@@ -96,3 +96,43 @@ def test_handler_persistence(tmp_path):
     assert [(r.id, r.score, r.payload) for r in a] == [(r.id, r.score, r.payload) for r in b] and len(a) == 7
     run(h2.create_collection("user/1", force_recreate=True))       # recreate ignores the stored files
     assert run(h2.get_collection_chunk_count("user/1")) == 0
+
+
+def test_handler_filters_root_query_semantics():
+    """filters = query_filter of the ROOT query (qdrant_handler.py:297, 371): the re-scored union of the
+    two branches is filtered, then cut to final_limit -- checked against the oracle tree run with
+    final_limit = |union| and filtered on the host; get_collection_chunk_count(filters) counts."""
+    from rag_application_amd import bm25
+    from rag_application_amd.handler import QdrantHandler
+    n, dim = 1500, 768
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    words = "vector search engine retrieval hybrid dense sparse index document chunk query ranking fusion".split()
+    rng = np.random.default_rng(8)
+    chunks, sp = [], []
+    for r in range(n):
+        text = " ".join(rng.choice(words, size=int(rng.integers(5, 30))))
+        idx, val = bm25.embed(text)
+        sp.append((idx, val))
+        chunks.append({"content": text, "dense_embedding": X[r].tolist(), "sparse_embedding": {"indices": idx, "values": val},
+                       "chunk_metadata": {"document_id": "d", "user_id": "u", "file_name": f"f{r % 5}.txt", "mime_type": "text/plain",
+                                          "file_size": 1, "description": "", "file_path": "/x", "context_version": 1,
+                                          "chunk_number": r, "doc_summary": "s"}})
+    h = QdrantHandler()
+    run(h.store_document_vectors(chunks, "u"))
+    params = dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=60, dense_limit=40,
+                  quantized_limit=40, sparse_limit=50, final_limit=8, hnsw_ef=128)
+    flt = {"must": [{"key": "file_name", "match": {"any": ["f1.txt", "f3.txt"]}}], "must_not": [{"key": "chunk_number", "range": {"lt": 100}}]}
+    qi, qv = bm25.embed("hybrid dense sparse retrieval")
+    q = O.synth_dense(O.SEED_QUERY, 0, 1, dim)[0]
+    got = run(h.hybrid_search_batch("u", [q.tolist()], [{"indices": qi, "values": qv}], top_k=8, search_params=params, filters=flt))[0]
+    ora = O.OracleIndex(dim, (64, 128, 256))
+    ip = np.cumsum([0] + [len(i) for i, _ in sp])
+    ora.add(X, ip, np.concatenate([np.asarray(i, np.int64) for i, _ in sp]), np.concatenate([np.asarray(v, np.float32) for _, v in sp]))
+    es, ei = O.hybrid_tree(ora, q, np.asarray(qi), np.asarray(qv, np.float32), dict(params, final_limit=50))
+    keep = [(s, r) for s, r in zip(es, ei) if (r % 5 in (1, 3)) and not (r < 100)][:8]
+    assert len(keep) > 0 and [p.payload["chunk_number"] for p in got] == [int(r) for _, r in keep]
+    np.testing.assert_array_equal(np.array([p.score for p in got], np.float32).view(np.uint32),
+                                  np.array([s for s, _ in keep], np.float32).view(np.uint32))
+    assert run(h.get_collection_chunk_count("u", filters=flt)) == sum(1 for r in range(n) if r % 5 in (1, 3) and r >= 100)
+    assert run(h.hybrid_search("u", "q", q.tolist(), {"indices": qi, "values": qv}, top_k=3, search_params=params,
+                               filters={"bogus": []})) == []          # bad filter: logged, [] (:384-386)

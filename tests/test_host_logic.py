@@ -170,3 +170,33 @@ def test_encode_sparse_batch_matches_single():
     h2 = EmbeddingHandler()
     many = asyncio.run(h2.encode_sparse_batch(texts))
     assert [(list(a.indices), list(a.values)) for a in one] == [(list(b.indices), list(b.values)) for b in many]
+
+
+def test_payload_filter_semantics():
+    """rag_application_amd/filters.py: the Qdrant Filter model restated (qdrant_handler.py:297, 466)."""
+    from rag_application_amd.filters import matches
+    p = {"file_name": "a.txt", "page_number": 3, "tags": ["x", "y"], "content": "Hybrid dense retrieval",
+         "meta": {"lang": "en", "score": 0.5}, "none": None, "empty": []}
+    assert matches(p, None) and matches(p, {})
+    assert matches(p, {"must": [{"key": "file_name", "match": {"value": "a.txt"}}]})
+    assert not matches(p, {"must": [{"key": "file_name", "match": {"value": "b.txt"}}]})
+    assert matches(p, {"must": [{"key": "tags", "match": {"value": "y"}}]})                 # list payload: any element
+    assert matches(p, {"must": [{"key": "tags", "match": {"any": ["q", "x"]}}]})
+    assert not matches(p, {"must": [{"key": "tags", "match": {"except": ["x"]}}]})
+    assert matches(p, {"must": [{"key": "file_name", "match": {"except": ["z"]}}]})
+    assert matches(p, {"must": [{"key": "content", "match": {"text": "dense hybrid"}}]})
+    assert matches(p, {"must": [{"key": "page_number", "range": {"gte": 3, "lt": 4}}]})
+    assert not matches(p, {"must": [{"key": "page_number", "range": {"gt": 3}}]})
+    assert matches(p, {"must": [{"key": "meta.lang", "match": {"value": "en"}}, {"key": "meta.score", "range": {"lte": 0.5}}]})
+    assert not matches(p, {"must": [{"key": "missing", "match": {"value": 1}}]})
+    assert matches(p, {"must_not": [{"key": "missing", "match": {"value": 1}}]})
+    assert matches(p, {"should": [{"key": "file_name", "match": {"value": "zzz"}}, {"key": "page_number", "match": {"value": 3}}]})
+    assert not matches(p, {"should": [{"key": "file_name", "match": {"value": "zzz"}}]})
+    assert matches(p, {"must": [{"is_empty": {"key": "empty"}}, {"is_empty": {"key": "missing"}}, {"is_null": {"key": "none"}}]})
+    assert not matches(p, {"must": [{"is_null": {"key": "missing"}}]})
+    assert matches(p, {"must": [{"has_id": ["id-1", "id-2"]}]}, point_id="id-2") and not matches(p, {"must": [{"has_id": ["q"]}]}, "id-2")
+    assert matches(p, {"must": [{"should": [{"key": "page_number", "match": {"value": 9}}, {"key": "tags", "match": {"value": "x"}}]}]})
+    with pytest.raises(ValueError):
+        matches(p, {"min_should": {}})
+    with pytest.raises(ValueError):
+        matches(p, {"must": [{"key": "a", "geo_radius": {}}]})
