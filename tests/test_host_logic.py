@@ -200,3 +200,36 @@ def test_payload_filter_semantics():
         matches(p, {"min_should": {}})
     with pytest.raises(ValueError):
         matches(p, {"must": [{"key": "a", "geo_radius": {}}]})
+
+
+def test_local_hf_encoder_unmasked_mean_and_rerank(tmp_path):
+    """LocalHFEncoder on a tiny randomly initialised BERT saved locally (no network): embed_text is the
+    UNMASKED mean of last_hidden_state over the padded batch (huggingface.py:165-170), the "reranker"
+    is mean-pooled query . docs with argsort descending (:172-189)."""
+    torch = pytest.importorskip("torch")
+    tr = pytest.importorskip("transformers")
+    from rag_application_amd.embedding import EmbeddingHandler, LocalHFEncoder
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + "hybrid dense sparse retrieval engine kernel wave front the a of query document".split()
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    tok = tr.BertTokenizer(str(tmp_path / "vocab.txt"))
+    tok.save_pretrained(str(tmp_path))
+    torch.manual_seed(0)
+    cfg = tr.BertConfig(vocab_size=len(vocab), hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                        intermediate_size=64, max_position_embeddings=64)
+    tr.BertModel(cfg).save_pretrained(str(tmp_path))
+    enc = LocalHFEncoder(str(tmp_path), device="cpu")
+    texts = ["hybrid dense sparse retrieval", "kernel", "the query of a document engine wave front"]
+    got = np.asarray(asyncio.run(enc.embed_text(texts)), np.float32)
+    inputs = enc.tokenizer(texts, return_tensors="pt", padding=True, truncation=True)
+    with torch.no_grad():
+        ref = enc.model(**inputs).last_hidden_state.mean(dim=1).numpy()      # padding positions included
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+    assert got.shape == (3, 32)
+    order = enc.rerank_documents("dense retrieval", texts, max_tokens=100)
+    q = np.asarray(asyncio.run(enc.embed_text(["dense retrieval"])), np.float32)[0]
+    assert order == np.argsort(got @ q)[::-1].tolist()
+    assert enc.rerank_documents("x", [], 10) == []
+    # through the EmbeddingHandler drop-in: model_name = local path
+    h = EmbeddingHandler(model_name=str(tmp_path))
+    out = asyncio.run(h.encode_dense(texts[0]))
+    assert len(out) == 1 and len(out[0]) == 32
