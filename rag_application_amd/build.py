@@ -10,7 +10,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libhx.so")
-SOURCES = ["scan.hip", "scan8.hip", "select.hip", "prep.hip", "sparse.hip", "spbuild.hip", "engine.hip", "bm25.cpp"]
+# (source, object, extra defines): sparse.hip is built for both segment sizes (kernels.hpp)
+SOURCES = [("scan.hip", "scan.o", ()), ("scan8.hip", "scan8.o", ()), ("select.hip", "select.o", ()),
+           ("prep.hip", "prep.o", ()),
+           ("sparse.hip", "sparse_v8k.o", ("HX_SP_VARIANT=v8k", "HX_SEG_DOCS=8192", "HX_SP_THREADS=512")),
+           ("sparse.hip", "sparse_v16k.o", ("HX_SP_VARIANT=v16k", "HX_SEG_DOCS=16384", "HX_SP_THREADS=1024")),
+           ("spbuild.hip", "spbuild.o", ()), ("engine.hip", "engine.o", ()), ("bm25.cpp", "bm25.o", ())]
 HEADERS = ["hx_common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "hx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function"]
@@ -37,11 +42,11 @@ def build(force: bool = False, verbose: bool = False, defines=(), lib: str = LIB
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
-    for s in SOURCES:
+    for s, o, extra in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ_, os.path.splitext(s)[0] + ".o")
+        obj = os.path.join(OBJ_, o)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *[f"-D{d}" for d in (*extra, *defines)], "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -53,7 +58,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), lib: str = LIB
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ_, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    objs = [os.path.join(OBJ_, o) for _, o, _ in SOURCES]
     if force or jobs or _stale(lib, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
     return lib

@@ -87,6 +87,8 @@ struct hx_index {
   bool sparse_stale = false;
   SparseBuildOut sp{};
   int n_segments = 0;
+  int seg_docs = SEG_DOCS_SMALL;      // segment size of the built inverted index
+  int seg_docs_force = 0;             // HX_DEBUG_SEG_DOCS (tests): 8192 / 16384, 0 = by size
   int64_t sp_docs_built = 0;
   Workspace ws;
   int64_t dense_fallbacks = 0, i8_fallbacks = 0, retries = 0;
@@ -104,6 +106,11 @@ struct hx_index {
 };
 
 namespace hx {
+
+void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st) {
+  if (a.ix.seg_docs == SEG_DOCS_LARGE) v16k::launch_sparse_score_variant(a, st);
+  else v8k::launch_sparse_score_variant(a, st);
+}
 
 // ---------------------------------------------------------------------------------
 // storage
@@ -179,8 +186,10 @@ static void finalize(hx_index* h, hipStream_t st) {
       HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows + 1, tail.data(), tail.size() * 8, hipMemcpyHostToDevice));
       h->sp_rows = rows;
     }
-    build_sparse_index(h->sp_indptr, h->sp_idx, h->sp_val, h->sp_rows, h->nnz, &h->sp, st);
-    h->n_segments = (int)((h->sp_rows + SEG_DOCS - 1) / SEG_DOCS);
+    // fewer, larger visits pay once a workgroup has enough segments to walk (kernels.hpp)
+    h->seg_docs = h->seg_docs_force ? h->seg_docs_force : (h->sp_rows >= 3000000 ? SEG_DOCS_LARGE : SEG_DOCS_SMALL);
+    build_sparse_index(h->sp_indptr, h->sp_idx, h->sp_val, h->sp_rows, h->nnz, h->seg_docs, &h->sp, st);
+    h->n_segments = (int)((h->sp_rows + h->seg_docs - 1) / h->seg_docs);
     h->sp_docs_built = h->sp_rows;
   }
   h->sparse_stale = false;
@@ -574,7 +583,8 @@ static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   finalize(h, st);
   if (h->n_segments == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
-  int parts = (512 + B - 1) / B;
+  const int slots = h->seg_docs == SEG_DOCS_LARGE ? 256 : 512;   // workgroups resident at once
+  int parts = (slots + B - 1) / B;
   parts = std::min(parts, h->n_segments);
   parts = std::min(parts, CAND_CAP / L);
   parts = std::max(parts, 1);
@@ -585,6 +595,7 @@ static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q
   a.ix.ptr = h->sp.ptr;
   a.ix.uterms = h->sp.uterms;
   a.ix.n_live = (int)h->sp.n_live;
+  a.ix.seg_docs = h->seg_docs;
   a.ix.n_docs = h->sp_docs_built;
   a.ix.n_segments = h->n_segments;
   a.ix.id_base = h->id_base;
@@ -596,8 +607,8 @@ static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q
   a.limit = L;
   a.out = pk;
   a.out_cnt = pc;
-  a.cand = (uint64_t*)h->ws.get(WS_SP_CAND, (size_t)B * parts * SP_CAND * 8);
-  a.park = (unsigned long long*)h->ws.get(WS_SP_PARK, (size_t)B * parts * (SEG_DOCS / 2) * 8);
+  a.cand = (uint64_t*)h->ws.get(WS_SP_CAND, (size_t)B * parts * h->seg_docs * 8);
+  a.park = (unsigned long long*)h->ws.get(WS_SP_PARK, (size_t)B * parts * (h->seg_docs / 2) * 8);
   a.q_order = (int*)h->ws.get(WS_SP_ORDER, (size_t)B * 4);
   a.stat_postings = nullptr;
   if (h->prof) {
@@ -779,6 +790,10 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
       throw Error("matryoshka sizes must be ascending multiples of 64, <= dim");
     }
     h->psize[i] = msizes[i];
+  }
+  if (const char* e = getenv("HX_DEBUG_SEG_DOCS")) {       // tests: force a segment size
+    const int v = atoi(e);
+    if (v == SEG_DOCS_SMALL || v == SEG_DOCS_LARGE) h->seg_docs_force = v;
   }
   if (const char* e = getenv("HX_DEBUG_SCAN8_LOGCAP")) {   // tests: force the log-overflow path
     const int v = atoi(e);

@@ -40,7 +40,20 @@
 #include "hx_common.hpp"
 #include "kernels.hpp"
 
+// Compiled twice (rag_application_amd/build.py): -DHX_SP_VARIANT=v8k -DHX_SEG_DOCS=8192
+// -DHX_SP_THREADS=512 and -DHX_SP_VARIANT=v16k -DHX_SEG_DOCS=16384 -DHX_SP_THREADS=1024.
+#ifndef HX_SP_VARIANT
+#define HX_SP_VARIANT v8k
+#endif
+#ifndef HX_SEG_DOCS
+#define HX_SEG_DOCS 8192
+#endif
+
 namespace hx {
+namespace HX_SP_VARIANT {
+
+constexpr int SEG_DOCS = HX_SEG_DOCS;   // docs per index segment (LDS accumulator: 8 B per doc)
+constexpr int SP_CAND = SEG_DOCS;       // per-workgroup candidate buffer (keys, global memory)
 
 // Diagnostic build only (-DHX_SP_STAMP): lane 0 of waves 0 and 3 accumulate s_memtime deltas per
 // phase into a debug buffer of its own (never read by the kernel, never in a timed build).
@@ -625,14 +638,15 @@ __global__ void k_sparse_order(const int64_t* q_indptr, int B, int* q_order) {
   }
 }
 
-#ifdef HX_SP_STAMP
+#if defined(HX_SP_STAMP) && HX_SEG_DOCS == 8192
 extern "C" int hx_debug_sp_stamps(unsigned long long* out_host, int n) {
   return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_sp_stamps), (size_t)n * 8);
 }
 #endif
 
-void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st) {
+void launch_sparse_score_variant(const SparseQueryArgs& a, hipStream_t st) {
   if (a.B <= 0) return;
+  HX_CHECK(a.ix.seg_docs == SEG_DOCS, "sparse: index built for another segment size");
   HX_CHECK(a.limit * 2 <= SP_CAND, "sparse: limit too large");
   if (a.q_order) {
     hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, st, a.q_indptr, a.B, a.q_order);
@@ -642,4 +656,5 @@ void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st) {
   HX_HIP(hipGetLastError());
 }
 
+}  // namespace HX_SP_VARIANT
 }  // namespace hx

@@ -45,22 +45,22 @@ __global__ void k_make_pairs(const int64_t* indptr, const int32_t* idx, const fl
 }
 
 // sorted payloads -> postings {document index inside its segment, weight bits}
-__global__ void k_make_postings(const uint64_t* pay, int64_t nnz, uint2* post) {
+__global__ void k_make_postings(const uint64_t* pay, int64_t nnz, uint32_t seg_docs, uint2* post) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
   const uint64_t p = pay[i];
-  post[i] = make_uint2((uint32_t)(p >> 32) % (uint32_t)SEG_DOCS, (uint32_t)p);
+  post[i] = make_uint2((uint32_t)(p >> 32) % seg_docs, (uint32_t)p);
 }
 
 // one workgroup per live term: ptr[t][s] = first posting of the term's run [b, e) whose document
-// is >= s * SEG_DOCS (binary search over the sorted payloads), s = 0 .. nseg
+// is >= s * seg_docs (binary search over the sorted payloads), s = 0 .. nseg
 __global__ __launch_bounds__(256) void k_fill_ptr(const uint64_t* pay, const uint64_t* run_off,
-                                                  const uint32_t* run_len, int nseg, uint32_t* ptr) {
+                                                  const uint32_t* run_len, int nseg, int seg_docs, uint32_t* ptr) {
   const int64_t t = blockIdx.x;
   const uint64_t b = run_off[t], e = b + run_len[t];
   uint32_t* row = ptr + t * (int64_t)(nseg + 1);
   for (int s = threadIdx.x; s <= nseg; s += 256) {
-    const uint64_t first_doc = (uint64_t)s * SEG_DOCS;
+    const uint64_t first_doc = (uint64_t)s * (uint64_t)seg_docs;
     uint64_t lo = b, hi = e;
     while (lo < hi) {
       const uint64_t mid = (lo + hi) >> 1;
@@ -71,12 +71,13 @@ __global__ __launch_bounds__(256) void k_fill_ptr(const uint64_t* pay, const uin
 }
 
 void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,
-                        int64_t nnz, SparseBuildOut* out, hipStream_t st) {
+                        int64_t nnz, int seg_docs, SparseBuildOut* out, hipStream_t st) {
   *out = SparseBuildOut{};
   if (nnz <= 0 || n_docs <= 0) return;
   HX_CHECK(nnz < (int64_t)0xFFFFFFFFll, "sparse index: nnz per shard must be < 2^32");
   HX_CHECK(n_docs < (int64_t)0xFFFFFFFFll, "sparse index: documents per shard must be < 2^32");
-  const int64_t nseg = (n_docs + SEG_DOCS - 1) / SEG_DOCS;
+  HX_CHECK(seg_docs == SEG_DOCS_SMALL || seg_docs == SEG_DOCS_LARGE, "bad segment size");
+  const int64_t nseg = (n_docs + seg_docs - 1) / seg_docs;
 
   DevBuf k_in(nnz * 4), k_out(nnz * 4), p_in(nnz * 8), p_out(nnz * 8);
   hipLaunchKernelGGL(k_make_pairs, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, indptr, idx, val,
@@ -120,13 +121,13 @@ void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* 
   const int64_t ptr_entries = (int64_t)n_live * (nseg + 1);
   HX_HIP(hipMalloc((void**)&out->ptr, (size_t)ptr_entries * 4));
   hipLaunchKernelGGL(k_fill_ptr, dim3((unsigned)n_live), dim3(256), 0, st, p_out.as<uint64_t>(), offs.as<uint64_t>(),
-                     counts.as<uint32_t>(), (int)nseg, out->ptr);
+                     counts.as<uint32_t>(), (int)nseg, seg_docs, out->ptr);
   HX_HIP(hipGetLastError());
   HX_HIP(hipMalloc((void**)&out->uterms, (size_t)n_live * 4));
   HX_HIP(hipMemcpyAsync(out->uterms, uterms.p, (size_t)n_live * 4, hipMemcpyDeviceToDevice, st));
   HX_HIP(hipMalloc((void**)&out->post, (size_t)nnz * sizeof(uint2)));
   hipLaunchKernelGGL(k_make_postings, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p_out.as<uint64_t>(),
-                     nnz, out->post);
+                     nnz, (uint32_t)seg_docs, out->post);
   HX_HIP(hipGetLastError());
   HX_HIP(hipStreamSynchronize(st));
   out->n_live = (int64_t)n_live;

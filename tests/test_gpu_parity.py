@@ -378,12 +378,15 @@ def test_golden_fixtures_through_the_abi(eng, torch_mod, synth_tables):
     ix.close()
 
 
-def test_sparse_cold_paths(eng, torch_mod):
-    """Sparse scoring beyond the pipelined fast path: a term held by EVERY document with
+@pytest.mark.parametrize("seg_docs", [8192, 16384])
+def test_sparse_cold_paths(eng, torch_mod, monkeypatch, seg_docs):
+    """Both builds of the sparse kernel (8192- and 16384-document segments; the engine picks by index
+    size, HX_DEBUG_SEG_DOCS forces one).  Sparse scoring beyond the pipelined fast path: a term held by EVERY document with
     equal weights (runs longer than a workgroup, 8192 tied survivors per segment: the
     two-pass harvest and the id-ascending tie rule), queries with more than 12 terms (the
     generic loop), negative weights, a term nobody holds, an empty query."""
-    n, dim = 20000, 64
+    monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
+    n, dim = 40000, 64
     rng = np.random.default_rng(9)
     vocab = 300
     indptr, idx, val = [0], [], []
@@ -578,3 +581,24 @@ def test_save_load_round_trip(eng, torch_mod, synth_tables, tmp_path):
         eng.HxIndex.load(bad)
     ix.close()
     ld.close()
+
+
+@pytest.mark.parametrize("seg_docs", [8192, 16384])
+def test_sparse_both_segment_sizes(eng, torch_mod, synth_tables, monkeypatch, seg_docs):
+    """The synthetic Zipf corpus through either sparse build: 60k documents, 300 queries, top-100."""
+    from oracle import c_oracle as CO
+    monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
+    n, B, L = 60000, 300, 100
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    ix = eng.HxIndex(64, ())
+    ix.add(O.synth_dense(5, 0, n, 64), ip, si.astype(np.int32), sv)
+    assert ix.stats()["n_segments"] in (0, (n + seg_docs - 1) // seg_docs)
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    es, ei, ec = CO.InvIndex(ip, si, sv).search(qip, qsi, qsv, L)
+    keys, cnt = ix.search_sparse(torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(),
+                                 torch_mod.from_numpy(qsv).cuda(), L)
+    assert ix.stats()["n_segments"] == (n + seg_docs - 1) // seg_docs
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"sparse seg={seg_docs} b={b}")
+    ix.close()
