@@ -1033,11 +1033,15 @@ int hx_merge(int32_t device, const uint64_t* in_keys, int32_t stride, const int3
   HX_CHECK(limit >= 1 && limit <= MAX_LIMIT, "limit out of range [1, 2048]");
   HX_HIP(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
-  // compact cannot alias distinct strides: go through scratch
-  uint64_t* tmp = (uint64_t*)static_ws(device).get(WS_RS_TMP, (size_t)B * stride * 8);
-  HX_HIP(hipMemcpyAsync(tmp, in_keys, (size_t)B * stride * 8, hipMemcpyDeviceToDevice, st));
-  launch_compact(tmp, stride, in_counts, B, std::min(limit, stride), dedupe, keys_dev, limit, counts_dev,
-                 nullptr, stride, st);
+  // compact cannot work in place across distinct strides: overlapping buffers go through scratch
+  const uint64_t* src = in_keys;
+  if (in_keys < keys_dev + (size_t)B * limit && keys_dev < in_keys + (size_t)B * stride) {
+    uint64_t* tmp = (uint64_t*)static_ws(device).get(WS_RS_TMP, (size_t)B * stride * 8);
+    HX_HIP(hipMemcpyAsync(tmp, in_keys, (size_t)B * stride * 8, hipMemcpyDeviceToDevice, st));
+    src = tmp;
+  }
+  launch_compact(const_cast<uint64_t*>(src), stride, in_counts, B, std::min(limit, stride), dedupe, keys_dev, limit,
+                 counts_dev, nullptr, stride, st);
   HX_CATCH
 }
 

@@ -96,6 +96,121 @@ __global__ __launch_bounds__(NT) void k_compact(const uint64_t* __restrict__ key
   }
 }
 
+// ---------------------------------------------------------------------------------
+// compaction, short form: keep <= 256 of <= 2048 keys, no dedupe.  Same results as
+// k_compact, but no block-wide sort: every wave sorts 256 keys in registers (4 per lane;
+// strides below 4 are register swaps, the rest lane exchanges -- no LDS traffic of its
+// own, no barrier), then log2(NW) rounds fold the waves pairwise: max(A[i], B[255 - i])
+// of two descending runs is a bitonic run holding the best 256 of both, sorted again by
+// the last 8 stages.  One barrier per round instead of one per stage (66 at P = 2048).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t k64max(uint64_t a, uint64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint64_t k64min(uint64_t a, uint64_t b) { return a > b ? b : a; }
+// compare-exchange stage (k, j) of the descending bitonic network over i = lane * 4 + e
+template <int K, int J>
+__device__ __forceinline__ void w_cx(uint64_t (&v)[4], int lane) {
+  if constexpr (J < 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if ((e & J) == 0) {
+        const bool desc = K < 4 ? ((e & K) == 0) : (((lane * 4) & K) == 0);
+        const uint64_t mx = k64max(v[e], v[e ^ J]), mn = k64min(v[e], v[e ^ J]);
+        v[e] = desc ? mx : mn;
+        v[e ^ J] = desc ? mn : mx;
+      }
+    }
+  } else {
+    constexpr int LM = J >> 2;
+    const bool lower = (lane & LM) == 0;
+    const bool desc = ((lane * 4) & K) == 0;
+    const bool take_max = lower == desc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)v[e], LM, 64);
+      v[e] = take_max ? k64max(v[e], y) : k64min(v[e], y);
+    }
+  }
+}
+template <int K, int J>
+__device__ __forceinline__ void w_merge(uint64_t (&v)[4], int lane) {
+  w_cx<K, J>(v, lane);
+  if constexpr (J > 1) w_merge<K, J / 2>(v, lane);
+}
+template <int K>
+__device__ __forceinline__ void w_sort(uint64_t (&v)[4], int lane) {
+  if constexpr (K > 2) w_sort<K / 2>(v, lane);
+  w_merge<K, K / 2>(v, lane);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_compact_top256(const uint64_t* __restrict__ keys, int stride,
+                                                            const int* __restrict__ in_cnt, int keep,
+                                                            uint64_t* out_keys, int out_stride, int* out_cnt,
+                                                            float* tau, int tau_rank, int chk_rank, int* kept_io,
+                                                            int* underflow) {
+  __shared__ uint64_t buf[NW > 1 ? NW * 256 : 1];
+  __shared__ int s_tot[NW];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int n = in_cnt ? in_cnt[b] : stride;
+  const int n_raw = n;
+  n = n < stride ? n : stride;
+  n = n < NW * 256 ? n : NW * 256;
+  const uint64_t* src = keys + (int64_t)b * stride;
+  uint64_t v[4];
+  int tot = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {   // the order inside an unsorted run is free: coalesced loads
+    const int i = w * 256 + e * 64 + lane;
+    v[e] = i < n ? src[i] : 0ull;
+    tot += __popcll(__ballot(v[e] != 0ull));
+  }
+  if (n > w * 256) w_sort<256>(v, lane);
+  if (NW > 1) {
+    if (lane == 0) s_tot[w] = tot;
+#pragma unroll
+    for (int s = 0; (1 << s) < NW; ++s) {
+      const int m = (2 << s) - 1;
+      if ((w & m) == (1 << s)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) buf[w * 256 + lane * 4 + e] = v[e];
+      }
+      __syncthreads();   // also: every wave's loads have landed before any store below (in-place use)
+      const int pw = w + (1 << s);
+      if ((w & m) == 0 && n > pw * 256) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = k64max(v[e], buf[pw * 256 + 255 - (lane * 4 + e)]);
+        w_merge<256, 128>(v, lane);
+      }
+    }
+    tot = 0;
+#pragma unroll
+    for (int x = 0; x < NW; ++x) tot += s_tot[x];
+  }
+  uint64_t* o = out_keys + (int64_t)b * out_stride;
+  const int kept = tot < keep ? tot : keep;
+  for (int i = 256 + tid; i < out_stride; i += NW * 64) o[i] = 0ull;
+  if (w == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = lane * 4 + e;
+      if (i < out_stride) o[i] = i < kept ? v[e] : 0ull;   // empty slots are 0
+    }
+    const int kr = tau_rank - 1;
+    const uint64_t mine = (kr & 3) == 0 ? v[0] : ((kr & 3) == 1 ? v[1] : ((kr & 3) == 2 ? v[2] : v[3]));
+    const uint64_t kth = (uint64_t)__shfl((unsigned long long)mine, kr >> 2, 64);
+    if (lane == 0) {
+      out_cnt[b] = kept;
+      if (tau) tau[b] = (tot >= keep && keep > 0) ? key_score(kth) : -__builtin_inff();
+      if (kept_io) {   // see k_compact
+        const int prev = kept_io[b];
+        if (chk_rank > 0 && prev >= keep && chk_rank + (n_raw - prev) < keep) underflow[b] = 1;
+        kept_io[b] = kept;
+      }
+    }
+  }
+}
+
 void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int keep, int dedupe,
                     uint64_t* out_keys, int out_stride, int* out_cnt, float* tau, int max_cnt_hint,
                     hipStream_t st, int tau_rank, int chk_rank, int* kept_io, int* underflow) {
@@ -104,6 +219,20 @@ void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int ke
   int P = next_pow2(m < 256 ? 256 : m);
   HX_CHECK(P <= CAND_CAP, "compact: list longer than CAND_CAP");
   HX_CHECK(keep <= out_stride, "compact: keep > out_stride");
+  if (!dedupe && keep >= 1 && keep <= 256 && P <= 2048) {   // short form; the tau rank is <= keep
+    if (tau_rank <= 0 || tau_rank > keep) tau_rank = keep;
+    HX_CHECK(!kept_io || underflow, "compact: kept_io without an underflow flag array");
+#define HX_TOP256(NW)                                                                                          \
+  hipLaunchKernelGGL(k_compact_top256<NW>, dim3(B), dim3(NW * 64), 0, st, keys, stride, in_cnt, keep, out_keys, \
+                     out_stride, out_cnt, tau, tau_rank, chk_rank, kept_io, underflow)
+    if (P <= 256) HX_TOP256(1);
+    else if (P <= 512) HX_TOP256(2);
+    else if (P <= 1024) HX_TOP256(4);
+    else HX_TOP256(8);
+#undef HX_TOP256
+    HX_HIP(hipGetLastError());
+    return;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     HX_HIP(hipFuncSetAttribute((const void*)k_compact<256>, hipFuncAttributeMaxDynamicSharedMemorySize,

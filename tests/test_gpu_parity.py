@@ -167,6 +167,38 @@ def test_rescore_rrf_merge(small, eng, torch_mod):
         np.testing.assert_array_equal(keys[b].cpu().numpy().view(np.uint64)[:len(u)], u)
 
 
+@pytest.mark.parametrize("stride", [100, 256, 257, 600, 1024, 1500, 2048, 4096])
+@pytest.mark.parametrize("dedupe", [False, True])
+def test_compaction_all_sizes(eng, torch_mod, stride, dedupe):
+    """hx_merge == sorted (descending) distinct non-zero keys of each list, cut to the limit: the
+    in-register short form (limit <= 256 of <= 2048 keys) and the LDS sort give the same lists."""
+    rng = np.random.default_rng(1000 + stride)
+    B = 37
+    pool = rng.integers(1, 2 ** 63 - 1, size=(B, stride), dtype=np.int64)
+    pool[rng.random((B, stride)) < 0.15] = 0                  # empty slots anywhere in a list
+    if dedupe:
+        pool[:, stride // 2:] = pool[:, :stride - stride // 2]  # every key twice
+    cnt = rng.integers(0, stride + 1, size=B).astype(np.int32)
+    cnt[0], cnt[1], cnt[2] = 0, stride, 1
+    for limit in (1, 10, 150, 256, 300):
+        if limit > stride:
+            continue
+        for counts in (None, cnt):
+            keys, kc = eng.merge(torch_mod.from_numpy(pool).cuda(),
+                                 None if counts is None else torch_mod.from_numpy(counts).cuda(), limit, dedupe=dedupe)
+            keys = keys.cpu().numpy().view(np.uint64)
+            kc = kc.cpu().numpy()
+            for b in range(B):
+                n = stride if counts is None else int(counts[b])
+                u = pool[b, :n].view(np.uint64)
+                u = u[u != 0]
+                u = np.unique(u)[::-1] if dedupe else np.sort(u)[::-1]
+                u = u[:limit]
+                assert kc[b] == len(u), (stride, limit, b)
+                np.testing.assert_array_equal(keys[b, :len(u)], u)
+                assert not keys[b, len(u):].any()
+
+
 @pytest.mark.parametrize("pname", ["mcp", "fallback"])
 def test_hybrid_tree(small, eng, torch_mod, synth_tables, pname):
     ora, ix, _ = small
