@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <functional>
 #include <map>
 #include <tuple>
 #include <cmath>
@@ -478,11 +479,20 @@ static void retry_subset(hx_index* h, const float* q_dev, const std::vector<int>
   }
 }
 
-static void search_dense(hx_index* h, const float* q_dev, int B, int prefix, int L, uint64_t* out_keys,
-                         int* out_cnt, hipStream_t st, int level = 0) {
+// `between` (optional): independent work of the caller, enqueued after this stage's kernels and BEFORE
+// the host reads the failure flags -- so the device has work while the host waits, and the stream is
+// still full when it returns.  It may consume out_keys speculatively: the return value says whether a
+// retry or the exact path rewrote rows of out_keys after `between` ran (then the caller redoes it).
+static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int L, uint64_t* out_keys,
+                         int* out_cnt, hipStream_t st, int level = 0,
+                         const std::function<void()>& between = std::function<void()>()) {
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
-  if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  if (h->n == 0) {
+    zero_outputs(out_keys, out_cnt, B, L, st);
+    if (between) between();
+    return false;
+  }
   const int wo = 1000 * level;  // workspace slots of this level
   const MatrixRef m = pick_matrix(h, prefix);
   const int bn = scan_bn(B);
@@ -521,23 +531,27 @@ static void search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     launch_compact(cand2, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
     HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
     launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st);
+    if (between) between();
     sel = read_failures(h, fail, nfail, B, st);
     if (!sel.empty() && level == 0) {
       retry_subset(h, q_dev, sel, L, out_keys, out_cnt, st, level,
                    [&](const float* qs, int ns, uint64_t* ks, int* cs) {
                      search_dense(h, qs, ns, prefix, L, ks, cs, st, 1);
                    });
-      return;
+      return true;
     }
   } else {
     sel.resize((size_t)B);
     std::iota(sel.begin(), sel.end(), 0);
+    if (between) between();
   }
   if (!sel.empty()) {
     h->dense_fallbacks += (int64_t)sel.size();
     exact_range_fallback(h, KIND_F32, m.m32, m.dpad, m.dpad, qn, m.dpad, nullptr, sel, L, out_keys,
                          out_cnt, st);
+    return true;
   }
+  return false;
 }
 
 static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* out_keys, int* out_cnt,
@@ -679,10 +693,17 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     int* Dc = cnts(WS_T_ACNT);
     uint64_t* S = keys(WS_T_B, p->sparse_limit);
     int* Sc = cnts(WS_T_BCNT);
-    search_dense(h, qd, B, 0, p->dense_limit, D, Dc, st);
-    search_sparse(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
-    rrf(h, D, p->dense_limit, Dc, S, p->sparse_limit, Sc, B, rk, p->rrf_rank_base, p->final_limit, out_keys,
-        out_cnt, st, w);
+    // the sparse stage and the fusion are enqueued before the host looks at the dense stage's
+    // failure flags (no idle device while it does); the fusion is redone if a retry patched D
+    auto fuse = [&]() {
+      rrf(h, D, p->dense_limit, Dc, S, p->sparse_limit, Sc, B, rk, p->rrf_rank_base, p->final_limit, out_keys,
+          out_cnt, st, w);
+    };
+    const bool patched = search_dense(h, qd, B, 0, p->dense_limit, D, Dc, st, 0, [&]() {
+      search_sparse(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+      fuse();
+    });
+    if (patched) fuse();
     return;
   }
   // --- matryoshka cascade (qdrant_handler.py:305-330)

@@ -528,15 +528,16 @@ __global__ __launch_bounds__(1024) void k_scatter_log(const uint4* __restrict__ 
   const int nloc = nq_tiles * 64;                     // queries of the group: q = qt*256 + wn*64 + j
   for (int i = tid; i < nloc; i += 1024) lcnt[i] = 0;
   __syncthreads();
+  static_assert(2 * S8_SB == 1024 / 64, "one wave of the workgroup per log");
+  const int l = tid >> 6, lane = tid & 63;            // wave l walks log l: the 16 logs advance together
+  const int sb = sb0 + (l >> 1);
+  const int w = sb * 8 + (l & 1) * 4 + wn;            // waves wn and wn + 4 of the scan workgroup
+  int n = sb < n_scan_blocks ? hitcnt[w] : 0;
+  n = n < logcap ? n : logcap;
+  const uint4* base = log + (int64_t)w * logcap * ENTRY;
   for (int pass = 0; pass < 2; ++pass) {
-    for (int l = 0; l < 2 * S8_SB; ++l) {
-      const int sb = sb0 + (l >> 1);
-      if (sb >= n_scan_blocks) break;
-      const int w = sb * 8 + (l & 1) * 4 + wn;        // waves wn and wn + 4 of the scan workgroup
-      int n = hitcnt[w];
-      n = n < logcap ? n : logcap;
-      const uint4* base = log + (int64_t)w * logcap * ENTRY;
-      for (int i = tid; i < n; i += 1024) {
+    {
+      for (int i = lane; i < n; i += 64) {
         const uint4* e = base + (int64_t)i * ENTRY;
         const uint4 h = e[0];
         const int q = (int)h.x;

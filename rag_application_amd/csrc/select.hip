@@ -258,7 +258,22 @@ void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int ke
 __device__ __forceinline__ float wave_spec_dot(const float* __restrict__ x, const float* __restrict__ q,
                                                int dim_pad, int lane) {
   float p = 0.0f;
-  for (int j = 0; j < dim_pad; j += 64) p = __fadd_rn(p, __fmul_rn(x[j + lane], q[j + lane]));
+  if (dim_pad <= 1024) {
+    // all loads of the row first (a row is one dependent round trip, not dim_pad / 64 of them); the
+    // sum keeps the order of the spec
+    float xv[16], qv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool in = i * 64 < dim_pad;
+      xv[i] = in ? x[i * 64 + lane] : 0.0f;
+      qv[i] = in ? q[i * 64 + lane] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i * 64 < dim_pad) p = __fadd_rn(p, __fmul_rn(xv[i], qv[i]));
+  } else {
+    for (int j = 0; j < dim_pad; j += 64) p = __fadd_rn(p, __fmul_rn(x[j + lane], q[j + lane]));
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) p = __fadd_rn(p, __shfl_down(p, off, 64));
   return __fadd_rn(p, 0.0f);  // lane 0 holds the result

@@ -75,8 +75,10 @@ class ShardedIndex:
     # -- whole queries -----------------------------------------------------------------------
     def hybrid_h1(self, q, q_indptr, q_idx, q_val, dense_limit=100, sparse_limit=100, limit=10,
                   rrf_k=2.0, rank_base=0):
-        dk, dc = self.local.search_dense(q, dense_limit)
+        # sparse first: the dense stage ends with a host read of its failure flags, and the device
+        # should not sit idle behind that read with the sparse stage still to be enqueued
         sk, sc = self.local.search_sparse(q_indptr, q_idx, q_val, sparse_limit)
+        dk, dc = self.local.search_dense(q, dense_limit)
         if self.world > 1:  # one exchange carries both lists
             allk = self.gather(torch.cat([dk, sk], dim=1)).reshape(q.shape[0], self.world, -1)
             dk, dc = self.ops.merge(allk[:, :, :dense_limit].reshape(q.shape[0], -1), None, dense_limit, False)

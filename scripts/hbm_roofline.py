@@ -2,7 +2,7 @@
 over 10M x 768 with B in {1, 8, 32} queries per pass.  Prints one JSON object:
 algorithmic bytes of the fp16 / int8 scan (rows*row_bytes + B*row_bytes) / HIP-event kernel time."""
 import sys, json, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from rag_application_amd import engine as eng, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 D = 768

@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0,'.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import oracle as O
 from rag_application_amd import engine as eng
 N = int(sys.argv[1]); B = int(sys.argv[2]); D = int(sys.argv[3]) if len(sys.argv)>3 else 768

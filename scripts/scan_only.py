@@ -1,6 +1,6 @@
 """Diagnostic: a few fp16 scans (for rocprofv3 --pmc runs).  argv: rows dim batch reps"""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from rag_application_amd import engine as eng, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 768

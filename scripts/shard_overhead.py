@@ -1,7 +1,7 @@
 """Diagnostic: per-rank step time of the row-sharded H1 path at N-GPU shard size, with the exchange
 replaced by a local stand-in (the lists repeated `world` times), i.e. everything but the wire."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from rag_application_amd import engine as eng, synth
 from rag_application_amd.distributed import ShardedIndex
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000

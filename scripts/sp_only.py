@@ -1,6 +1,6 @@
 """Runs only the sparse stage (for rocprofv3 --pmc on k_sparse_score)."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from rag_application_amd import engine as eng, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 B = 1024

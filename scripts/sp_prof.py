@@ -1,6 +1,6 @@
 """Diagnostic: sparse stage time, postings visited, algorithmic GB/s.  argv: rows [B]"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from rag_application_amd import engine as eng, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024

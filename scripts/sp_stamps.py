@@ -1,7 +1,7 @@
 """Diagnostic: per-phase cycle shares of k_sparse_score (needs the -DHX_SP_STAMP library built in-tree:
 python -c "from rag_application_amd import build; build.build(defines=('HX_SP_STAMP',), lib='rag_application_amd/csrc/build/libhx_stamp.so', objdir='rag_application_amd/csrc/build/stamp')")"""
 import os, sys, ctypes, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 os.environ["HX_LIB_PATH"] = os.path.abspath("rag_application_amd/csrc/build/libhx_stamp.so")
 import torch
 from rag_application_amd import engine as eng, synth, _lib
