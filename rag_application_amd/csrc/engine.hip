@@ -322,9 +322,6 @@ struct ProfScope {
 static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t* Q, int64_t row_bytes, int B,
                          int bn, const Geometry& g, uint64_t* cand, int* cnt, int* ovf, float* tau,
                          const float* rinv_q, hipStream_t st) {
-  launch_fill_f32(tau, B, -std::numeric_limits<float>::infinity(), st);
-  HX_HIP(hipMemsetAsync(cnt, 0, (size_t)B * 4, st));
-  HX_HIP(hipMemsetAsync(ovf, 0, (size_t)B * 4, st));
   ScanArgs a{};
   a.A = A;
   a.Q = Q;
@@ -367,20 +364,27 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   a.hitcnt = hitcnt;
   a.logcap = logcap;
   int* kept = (int*)h->ws.get(WS_KEPT, (size_t)B * 4);
-  HX_HIP(hipMemsetAsync(kept, 0, (size_t)B * 4, st));
   int64_t r0 = 0, r1 = std::min<int64_t>(h->n, g.C);
+  // threshold -inf, flags 0; the first chunk passes every row into slot (row - r0): its count is known
+  launch_scan_init(tau, cnt, ovf, kept, B, (int)(r1 - r0), st);
   int chk_rank = 0;   // rank whose score is the threshold of the chunk being scanned (0: none)
   while (r0 < h->n) {
     a.row_begin = r0;
     a.row_end = r1;
     a.hitlog = r0 > 0 ? hitlog : nullptr;   // the first chunk passes every row: k_scan, one slot per row
     a.all_pass = (r0 == 0 && r1 - r0 <= g.C) ? 1 : 0;
-    if (a.all_pass) launch_fill_i32(cnt, B, (int)(r1 - r0), st);
     {
       const double rows = (double)(r1 - r0);
       const double elems = kind == KIND_F16 ? (double)row_bytes / 2.0 : (double)row_bytes;
       ProfScope ps(h, st, kind, 2.0 * B * rows * elems, rows * (double)row_bytes + (double)B * row_bytes);
-      launch_scan(a, kind, bn, st);
+      if (a.all_pass && bn == 256) {
+        // a few thousand rows: 128 x 128 tiles give four times the workgroups of the 256 x 256 form
+        ScanArgs f = a;
+        f.nq_tiles = (int)(round_up(B, 256) / 128);
+        launch_scan(f, kind, 128, st);
+      } else {
+        launch_scan(a, kind, bn, st);
+      }
     }
     // rows per launch bounded so the kernel's 32-bit tile counters cannot wrap
     const int64_t next = std::min<int64_t>(h->n, std::min<int64_t>(r1 * g.grow, r1 + (1ll << 27)));

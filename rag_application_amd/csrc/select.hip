@@ -477,6 +477,20 @@ __global__ void k_fill(T* p, int64_t n, T v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+// per-query state of a chunked scan in one launch: threshold -inf, counts, flags
+__global__ void k_scan_init(float* tau, int* cnt, int* ovf, int* kept, int B, int cnt0) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  tau[b] = -__builtin_inff();
+  cnt[b] = cnt0;
+  ovf[b] = 0;
+  kept[b] = 0;
+}
+void launch_scan_init(float* tau, int* cnt, int* ovf, int* kept, int B, int cnt0, hipStream_t st) {
+  hipLaunchKernelGGL(k_scan_init, dim3((B + 255) / 256), dim3(256), 0, st, tau, cnt, ovf, kept, B, cnt0);
+  HX_HIP(hipGetLastError());
+}
+
 void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_fill<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
