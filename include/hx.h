@@ -144,6 +144,21 @@ int hx_rrf(int32_t device, const uint64_t* a_keys_dev, int32_t a_stride, const i
 int hx_merge(int32_t device, const uint64_t* in_keys_dev, int32_t stride, const int32_t* in_counts_dev,
              int32_t B, int32_t limit, int32_t dedupe,
              uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+/* Row-sharded H1 query, one process per GPU (the reference has no
+ * multi-device path -- these two calls bracket the one all-gather of the step):
+ *  hx_h1_local  the shard's dense top-`dense_limit` and sparse top-`sparse_limit` of every
+ *               query, side by side in keys_dev [B x (dense_limit + sparse_limit)]
+ *               (qdrant_handler.py:347-354 and the dense Prefetch of the H1 configuration;
+ *               0 = empty slot, ids are global: id_base + row);
+ *  hx_h1_fuse   gathered_dev [world x B x (dense_limit + sparse_limit)] (rank-major, as
+ *               all_gather_into_tensor leaves it): per query the global dense and sparse
+ *               lists (top of the union of the shards' lists), then RRF as hx_rrf. */
+int hx_h1_local(hx_index* h, const float* q_dev, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
+                const float* q_val_dev, int32_t B, int32_t dense_limit, int32_t sparse_limit,
+                uint64_t* keys_dev, void* stream);
+int hx_h1_fuse(int32_t device, const uint64_t* gathered_dev, int32_t world, int32_t B,
+               int32_t dense_limit, int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base,
+               uint64_t* keys_dev, int32_t* counts_dev, void* stream);
 /* keys -> (fp32 score, int64 id); empty slots give (-inf, -1) */
 int hx_unpack(int32_t device, const uint64_t* keys_dev, int64_t n, float* scores_dev,
               int64_t* ids_dev, void* stream);

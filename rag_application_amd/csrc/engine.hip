@@ -51,7 +51,8 @@ enum WsSlot {
   WS_NFAIL, WS_QSEL, WS_FB_KEYS, WS_FB_CNT, WS_FB_INCNT, WS_SP_PARTS, WS_SP_PCNT, WS_RAW, WS_RS_TMP,
   WS_T_A, WS_T_ACNT, WS_T_B, WS_T_BCNT, WS_T_C, WS_T_CCNT, WS_T_D, WS_T_DCNT, WS_T_E, WS_T_ECNT,
   WS_T_F, WS_T_FCNT, WS_T_G, WS_T_GCNT, WS_H_QD, WS_H_QIP, WS_H_QIX, WS_H_QV, WS_H_OUT, WS_H_OCNT,
-  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT, WS_KEPT
+  WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT, WS_KEPT,
+  WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC
 };
 
 template <typename T>
@@ -1067,6 +1068,52 @@ int hx_merge(int32_t device, const uint64_t* in_keys, int32_t stride, const int3
   }
   launch_compact(const_cast<uint64_t*>(src), stride, in_counts, B, std::min(limit, stride), dedupe, keys_dev, limit,
                  counts_dev, nullptr, stride, st);
+  HX_CATCH
+}
+
+int hx_h1_local(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix, const float* qv, int32_t B,
+                int32_t dense_limit, int32_t sparse_limit, uint64_t* keys_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && qd && qip && keys_dev && B > 0, "bad argument");
+  h->set_device();
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& w = h->ws;
+  uint64_t* D = (uint64_t*)w.get(WS_T_A, (size_t)B * dense_limit * 8);
+  int* Dc = (int*)w.get(WS_T_ACNT, (size_t)B * 4);
+  uint64_t* S = (uint64_t*)w.get(WS_T_B, (size_t)B * sparse_limit * 8);
+  int* Sc = (int*)w.get(WS_T_BCNT, (size_t)B * 4);
+  auto pack = [&]() { launch_concat(D, dense_limit, Dc, S, sparse_limit, Sc, B, keys_dev, st); };
+  // as in hybrid_query_dev: sparse + packing are enqueued before the host reads the dense flags
+  const bool patched = search_dense(h, qd, B, 0, dense_limit, D, Dc, st, 0, [&]() {
+    search_sparse(h, qip, qix, qv, B, sparse_limit, S, Sc, st);
+    pack();
+  });
+  if (patched) pack();
+  HX_CATCH
+}
+
+int hx_h1_fuse(int32_t device, const uint64_t* gathered, int32_t world, int32_t B, int32_t dense_limit,
+               int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base, uint64_t* keys_dev,
+               int32_t* counts_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(gathered && keys_dev && counts_dev && B > 0 && world >= 1, "bad argument");
+  HX_CHECK(dense_limit >= 1 && sparse_limit >= 1 && (int64_t)world * std::max(dense_limit, sparse_limit) <= CAND_CAP,
+           "h1_fuse: world x limit out of range [1, 8192]");
+  HX_CHECK(limit >= 1 && limit <= MAX_LIMIT, "limit out of range [1, 2048]");
+  HX_HIP(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& w = static_ws(device);
+  const int ds = world * dense_limit, ss = world * sparse_limit;
+  uint64_t* dall = (uint64_t*)w.get(WS_F_DALL, (size_t)B * ds * 8);
+  uint64_t* sall = (uint64_t*)w.get(WS_F_SALL, (size_t)B * ss * 8);
+  uint64_t* D = (uint64_t*)w.get(WS_F_D, (size_t)B * dense_limit * 8);
+  uint64_t* S = (uint64_t*)w.get(WS_F_S, (size_t)B * sparse_limit * 8);
+  int* Dc = (int*)w.get(WS_F_DC, (size_t)B * 4);
+  int* Sc = (int*)w.get(WS_F_SC, (size_t)B * 4);
+  launch_regroup(gathered, world, B, dense_limit, sparse_limit, dall, sall, st);
+  launch_compact(dall, ds, nullptr, B, dense_limit, 0, D, dense_limit, Dc, nullptr, ds, st);
+  launch_compact(sall, ss, nullptr, B, sparse_limit, 0, S, sparse_limit, Sc, nullptr, ss, st);
+  rrf(nullptr, D, dense_limit, Dc, S, sparse_limit, Sc, B, rrf_k, rank_base, limit, keys_dev, counts_dev, st, w);
   HX_CATCH
 }
 

@@ -109,6 +109,7 @@ void launch_unpack(const uint64_t* keys, int64_t n, float* scores, int64_t* ids,
 // out[b*(sa+sb) ...] = a-list then b-list (empty slots 0)
 void launch_concat(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride,
                    const int* b_cnt, int B, uint64_t* out, hipStream_t st);
+void launch_regroup(const uint64_t* g, int world, int B, int dl, int sl, uint64_t* d, uint64_t* s, hipStream_t st);
 void launch_scan_init(float* tau, int* cnt, int* ovf, int* kept, int B, int cnt0, hipStream_t st);
 void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st);

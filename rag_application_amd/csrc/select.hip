@@ -472,6 +472,23 @@ void launch_concat(const uint64_t* a, int a_stride, const int* a_cnt, const uint
   HX_HIP(hipGetLastError());
 }
 
+// gathered [world x B x (dl + sl)] (rank-major) -> dense [B x world*dl], sparse [B x world*sl]
+__global__ void k_regroup(const uint64_t* __restrict__ g, int world, int B, int dl, int sl,
+                          uint64_t* __restrict__ d, uint64_t* __restrict__ s) {
+  const int b = blockIdx.x, L = dl + sl;
+  for (int i = threadIdx.x; i < world * L; i += blockDim.x) {
+    const int r = i / L, j = i - r * L;
+    const uint64_t k = g[((int64_t)r * B + b) * L + j];
+    if (j < dl) d[(int64_t)b * world * dl + r * dl + j] = k;
+    else s[(int64_t)b * world * sl + r * sl + (j - dl)] = k;
+  }
+}
+void launch_regroup(const uint64_t* g, int world, int B, int dl, int sl, uint64_t* d, uint64_t* s, hipStream_t st) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_regroup, dim3(B), dim3(256), 0, st, g, world, B, dl, sl, d, s);
+  HX_HIP(hipGetLastError());
+}
+
 template <typename T>
 __global__ void k_fill(T* p, int64_t n, T v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -38,6 +38,11 @@ class ShardedIndex:
         if self.world == 1:
             return keys
         B, L = keys.shape
+        return self.gather_raw(keys).view(self.world, B, L).permute(1, 0, 2).reshape(B, -1)
+
+    def gather_raw(self, keys: torch.Tensor) -> torch.Tensor:
+        """[B, L] per rank -> [world*B, L], rank-major (what the all-gather leaves)."""
+        B, L = keys.shape
         out = torch.empty((self.world * B, L), dtype=keys.dtype, device=keys.device)   # rank-major concat
         if dist.get_backend(self.group) == "gloo":   # CPU tests / rehearsals: gloo has no flat all-gather on devices
             parts = list(out.view(self.world, B, L).unbind(0))
@@ -47,7 +52,7 @@ class ShardedIndex:
                 p.copy_(h)
         else:
             dist.all_gather_into_tensor(out, keys.contiguous(), group=self.group)
-        return out.view(self.world, B, L).permute(1, 0, 2).reshape(B, -1)
+        return out
 
     def _global(self, keys, limit, dedupe=False):
         if self.world == 1:
@@ -75,6 +80,11 @@ class ShardedIndex:
     # -- whole queries -----------------------------------------------------------------------
     def hybrid_h1(self, q, q_indptr, q_idx, q_val, dense_limit=100, sparse_limit=100, limit=10,
                   rrf_k=2.0, rank_base=0):
+        if hasattr(self.local, "h1_local") and hasattr(self.ops, "h1_fuse"):
+            # two ABI calls around the one exchange of the step: no per-stage host work in between
+            mine = self.local.h1_local(q, q_indptr, q_idx, q_val, dense_limit, sparse_limit)
+            allk = mine if self.world == 1 else self.gather_raw(mine)
+            return self.ops.h1_fuse(allk, self.world, dense_limit, sparse_limit, limit, rrf_k, rank_base)
         # sparse first: the dense stage ends with a host read of its failure flags, and the device
         # should not sit idle behind that read with the sparse stage still to be enqueued
         sk, sc = self.local.search_sparse(q_indptr, q_idx, q_val, sparse_limit)

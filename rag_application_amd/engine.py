@@ -189,6 +189,19 @@ class HxIndex:
                                           _ptr(keys), _ptr(cnt), _stream()))
         return keys, cnt
 
+    def h1_local(self, q: torch.Tensor, q_indptr: torch.Tensor, q_idx: torch.Tensor, q_val: torch.Tensor,
+                 dense_limit: int, sparse_limit: int) -> torch.Tensor:
+        """This shard's dense and sparse lists side by side, [B, dense_limit + sparse_limit] (hx_h1_local)."""
+        q = _need_cuda(q, torch.float32, "q")
+        q_indptr = _need_cuda(q_indptr, torch.int64, "q_indptr")
+        q_idx = _need_cuda(q_idx, torch.int32, "q_idx")
+        q_val = _need_cuda(q_val, torch.float32, "q_val")
+        B = q.shape[0]
+        keys = torch.empty((B, dense_limit + sparse_limit), dtype=torch.int64, device=q.device)
+        check(_lib.lib().hx_h1_local(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, dense_limit,
+                                     sparse_limit, _ptr(keys), _stream()))
+        return keys
+
     def rescore(self, q: torch.Tensor, cand_keys: torch.Tensor, cand_counts: Optional[torch.Tensor],
                 limit: int, prefix: int = 0):
         q = _need_cuda(q, torch.float32, "q")
@@ -238,6 +251,20 @@ def rrf(a_keys: torch.Tensor, a_cnt: torch.Tensor, b_keys: torch.Tensor, b_cnt: 
     check(_lib.lib().hx_rrf(dev.index or 0, _ptr(a_keys.contiguous()), a_keys.shape[1], _ptr(a_cnt),
                             _ptr(b_keys.contiguous()), b_keys.shape[1], _ptr(b_cnt), B, k, rank_base, limit,
                             _ptr(keys), _ptr(cnt), _stream()))
+    return keys, cnt
+
+
+def h1_fuse(gathered: torch.Tensor, world: int, dense_limit: int, sparse_limit: int, limit: int = 10,
+            k: float = 2.0, rank_base: int = 0):
+    """gathered: [world * B, dense_limit + sparse_limit], rank-major (all_gather_into_tensor of h1_local):
+    global dense and sparse lists, then RRF (hx_h1_fuse)."""
+    dev = gathered.device
+    gathered = gathered.contiguous()
+    B = gathered.shape[0] // world
+    keys = torch.empty((B, limit), dtype=torch.int64, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(_lib.lib().hx_h1_fuse(dev.index or 0, _ptr(gathered), world, B, dense_limit, sparse_limit, limit, k,
+                                rank_base, _ptr(keys), _ptr(cnt), _stream()))
     return keys, cnt
 
 

@@ -19,6 +19,7 @@ def fake_gather(keys):
     out = keys.contiguous().repeat(world, 1)           # stands in for all_gather_into_tensor
     return out.view(world, Bq, L).permute(1, 0, 2).reshape(Bq, -1)
 sh.gather = fake_gather
+sh.gather_raw = lambda keys: keys.contiguous().repeat(world, 1)
 hp = eng.make_params(dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=60, dense_limit=100,
                           quantized_limit=40, sparse_limit=100, final_limit=10, hnsw_ef=128), mode=eng.HX_MODE_H1)
 def timeit(f, n=10):

@@ -375,6 +375,20 @@ def test_two_shards_one_gpu_merge_equals_unsharded(eng, torch_mod, synth_tables)
     for b in range(B):
         es, ei = O.hybrid_tree(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], P)
         assert_list_equal(s_[b], i_[b], c_[b], es, ei, f"sharded tree b={b}")
+    # H1 through the two calls that bracket the exchange (hx_h1_local / hx_h1_fuse): the shards' packed
+    # lists stacked rank-major, as all_gather_into_tensor leaves them
+    allk = torch_mod.cat([s.h1_local(Qd, *tq, 40, 25) for s in shards], dim=0)
+    s_, i_, c_ = unpack_np(eng, *eng.h1_fuse(allk, 2, 40, 25, limit=10))
+    one = eng.HxIndex(dim, (64, 128))
+    one.add(X, ip, si.astype(np.int32), sv)
+    hp = eng.make_params(dict(P, matryoshka_256_limit=1, dense_limit=40, sparse_limit=25, final_limit=10),
+                         mode=eng.HX_MODE_H1)
+    s1, i1, c1 = unpack_np(eng, *one.hybrid_query(Qd, *tq, hp))
+    for b in range(B):
+        assert_list_equal(s_[b], i_[b], c_[b], s1[b, :c1[b]], i1[b, :c1[b]], f"sharded h1 vs one index b={b}")
+        es, ei = O.hybrid_h1(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], 40, 25, 10)
+        assert_list_equal(s_[b], i_[b], c_[b], es, ei, f"sharded h1 vs oracle b={b}")
+    one.close()
     for s in shards:
         s.close()
 
