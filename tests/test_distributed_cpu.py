@@ -97,6 +97,27 @@ class CpuOps:
         return keys_of(lists, limit)
 
 
+class FakeShardH1(FakeShard):
+    """... with the packed local H1 stage (engine.HxIndex.h1_local)"""
+
+    def h1_local(self, q, qip, qix, qv, dense_limit, sparse_limit):
+        return torch.cat([self.search_dense(q, dense_limit)[0], self.search_sparse(qip, qix, qv, sparse_limit)[0]],
+                         dim=1)
+
+
+class CpuOpsH1(CpuOps):
+    @staticmethod
+    def h1_fuse(gathered, world, dense_limit, sparse_limit, limit, k, rank_base):
+        """[world * B, dl + sl] rank-major -> global lists -> RRF (engine.h1_fuse / hx_h1_fuse)"""
+        B = gathered.shape[0] // world
+        g = gathered.view(world, B, dense_limit + sparse_limit)
+        d = g[:, :, :dense_limit].permute(1, 0, 2).reshape(B, -1)
+        sp = g[:, :, dense_limit:].permute(1, 0, 2).reshape(B, -1)
+        dk, dc = CpuOps.merge(d, None, dense_limit, False)
+        sk, sc = CpuOps.merge(sp, None, sparse_limit, False)
+        return CpuOps.rrf(dk, dc, sk, sc, limit, k, rank_base)
+
+
 def worker(rank, world, port, n, dim, B, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -116,6 +137,9 @@ def worker(rank, world, port, n, dim, B, ret):
     tk, tc = sh.hybrid_tree(Q, *tq, P)
     hk, hc = sh.hybrid_h1(Q, *tq, 40, 30, 10)
     dk, dc = sh.search_dense(Q, 15)
+    # the same H1 query through the two calls that bracket the single exchange of the step
+    h2k, h2c = ShardedIndex(FakeShardH1(ora, r0), ops=CpuOpsH1).hybrid_h1(Q, *tq, 40, 30, 10)
+    assert torch.equal(h2k, hk) and torch.equal(h2c, hc)
     ret[rank] = (tk.numpy(), tc.numpy(), hk.numpy(), hc.numpy(), dk.numpy(), dc.numpy())
     dist.barrier()
     dist.destroy_process_group()
