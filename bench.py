@@ -80,12 +80,13 @@ def cpu_baseline(wl, B, dim, tabs, cpu_rows, cpu_queries, gpu_check):
         out = [(ds[b, :dc[b]], di[b, :dc[b]]) for b in range(bs)]
     dt = time.perf_counter() - t0
     ok = None
+    recall = None
     if gpu_check is not None:
-        ok = bool(gpu_check(ns, bs, out))
+        ok, recall = gpu_check(ns, bs, out)
     return dict(value=bs / dt * (ns / rows), unit="queries/sec", cores=threads, kind="port",
                 sample=f"{bs} of {B} queries x rows [0,{ns}) of {rows} ({dt:.2f} s of CPU work); "
                        f"brute force is linear in rows, rate scaled by {ns}/{rows}",
-                parity_on_sample=ok)
+                parity_on_sample=ok, recall_at_10=recall)
 
 
 def main():
@@ -222,12 +223,14 @@ def main():
             s, i = eng.unpack(k)
             s, i, c = s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy()
             six.close()
-            ok = True
+            ok, hit, want = True, 0, 0
             for b in range(bs):
                 es, ei = cpu_lists[b]
                 ok &= int(c[b]) == len(ei) and np.array_equal(i[b, :len(ei)], ei) and \
                     np.array_equal(s[b, :len(ei)].view(np.uint32), np.asarray(es, np.float32).view(np.uint32))
-            return ok
+                hit += len(np.intersect1d(i[b, :int(c[b])], ei))      # recall@10 vs the brute-force lists
+                want += len(ei)
+            return bool(ok), (hit / want if want else None)
         cpu = cpu_baseline(wl, B, dim, tabs, args.cpu_rows, args.cpu_queries, gpu_check)
 
     if rank == 0:
@@ -244,6 +247,7 @@ def main():
                                      "fixed-point sums",
                        "sharding": f"rows/{world}", "nnz_per_shard": st["nnz"],
                        "exact_fallback_queries": st["dense_fallback_queries"], "build_s": round(t_build, 2)},
+            "recall_at_10": cpu["recall_at_10"] if cpu else None,   # vs brute force on the cpu_baseline sample
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
