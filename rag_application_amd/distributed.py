@@ -116,3 +116,35 @@ class ShardedIndex:
         rk, rc = self.ops.rrf(dk, dc, sk, sc, rrf_limit, rrf_k, rank_base)
         uk = torch.cat([ak, rk], dim=1)     # empty slots are 0 and are ignored downstream
         return self.rescore(q, uk, None, p["final_limit"], 0)
+
+
+class H1Pipeline:
+    """Consecutive H1 batches in flight ("overlap the gather of batch i with K3 of batch
+    i+1 on a second stream").  `submit` runs the local stage of a batch on the current stream and hands
+    its exchange + fusion to a side stream, so they run beside the local stage of the next batch; the
+    returned tensors are valid once `wait()` (or a device synchronize) has passed.  With one rank, or
+    without a HIP device (the gloo tests), it degenerates to `ShardedIndex.hybrid_h1`."""
+
+    def __init__(self, sh: ShardedIndex, dense_limit=100, sparse_limit=100, limit=10, rrf_k=2.0, rank_base=0):
+        self.sh = sh
+        self.args = (dense_limit, sparse_limit, limit, rrf_k, rank_base)
+        fast = hasattr(sh.local, "h1_local") and hasattr(sh.ops, "h1_fuse")
+        self.side = torch.cuda.Stream() if (sh.world > 1 and fast and torch.cuda.is_available()) else None
+
+    def submit(self, q, q_indptr, q_idx, q_val):
+        sh = self.sh
+        dl, sl, limit, rrf_k, rank_base = self.args
+        if self.side is None:
+            return sh.hybrid_h1(q, q_indptr, q_idx, q_val, dl, sl, limit, rrf_k, rank_base)
+        mine = sh.local.h1_local(q, q_indptr, q_idx, q_val, dl, sl)   # returns once the stage's flags are read
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            out = sh.ops.h1_fuse(sh.gather_raw(mine), sh.world, dl, sl, limit, rrf_k, rank_base)
+        mine.record_stream(self.side)
+        return out
+
+    def wait(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
