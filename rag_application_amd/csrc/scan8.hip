@@ -596,7 +596,9 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st) {
   const int64_t tiles = (n_rows + 255) / 256 * a.nq_tiles;
   HX_CHECK(tiles * (a.row_bytes >> 7) < (1ll << 31), "scan: launch too large");
   HX_CHECK(a.hitlog && a.hitcnt && a.logcap > 0, "scan8: no hit log");
-  int64_t g = tiles < 256 ? tiles : 256;
+  static const int grid_cap = getenv("HX_DEBUG_SCAN8_GRID") ? atoi(getenv("HX_DEBUG_SCAN8_GRID")) : 256;   // diagnostics
+  const int cap = (grid_cap >= 8 && grid_cap <= 256) ? grid_cap / 8 * 8 : 256;
+  int64_t g = tiles < cap ? tiles : cap;
   g = (g + 7) / 8 * 8;
 #ifdef HX_SCAN_DBG
   static const int dbg = getenv("HX_SCAN_DBG") ? atoi(getenv("HX_SCAN_DBG")) : 0;
