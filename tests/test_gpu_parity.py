@@ -690,3 +690,36 @@ def test_sparse_both_segment_sizes(eng, torch_mod, synth_tables, monkeypatch, se
     for b in range(B):
         assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"sparse seg={seg_docs} b={b}")
     ix.close()
+
+
+# ---- edges of the parameter space ------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,B,L,i8", [(12000, 4096, 260, 10, True),      # widest row the ABI takes
+                                          (20000, 128, 4100, 10, True),      # batch beyond scan8's LDS threshold table
+                                          (20000, 256, 150, 2048, True),     # largest limit
+                                          (1, 768, 140, 10, True),           # one row
+                                          (300, 1, 200, 5, False),           # one dimension: every cosine is +-1, all ties
+                                          (260, 64, 257, 300, True)])        # limit above the row count
+def test_extremes(eng, torch_mod, n, dim, B, L, i8):
+    """Dense and int8 stages at the limits of the ABI (dim 4096, batch 4100, limit 2048) and at degenerate
+    sizes, bit for bit against the C restatement."""
+    from oracle import c_oracle as CO
+    X = O.synth_dense(5, 0, n, dim)
+    Q = O.synth_dense(6, 0, B, dim)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    es, ei, ec = CO.search_dense(CO.cosine_preprocess(X), CO.cosine_preprocess(Q), L)
+    s, i, c = unpack_np(eng, *ix.search_dense(torch_mod.from_numpy(Q).cuda(), L))
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"dense n={n} dim={dim} b={b}")
+    ix.close()
+    if i8:
+        Xu, Qu = CO.cosine_preprocess(X), CO.cosine_preprocess(Q)
+        ix8 = eng.HxIndex(dim, ())
+        ix8.add(Xu)
+        X8, rx = CO.quantize_i8(Xu)
+        Q8, rq = CO.quantize_i8(Qu)
+        es, ei, ec = CO.search_i8(X8, rx, Q8, rq, L)
+        s, i, c = unpack_np(eng, *ix8.search_i8(torch_mod.from_numpy(Qu).cuda(), L))
+        for b in range(B):
+            assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"i8 n={n} dim={dim} b={b}")
+        ix8.close()
