@@ -16,7 +16,7 @@ SOURCES = [("scan.hip", "scan.o", ()), ("scan8.hip", "scan8.o", ()), ("select.hi
            ("sparse.hip", "sparse_v8k.o", ("HX_SP_VARIANT=v8k", "HX_SEG_DOCS=8192", "HX_SP_THREADS=512")),
            ("sparse.hip", "sparse_v16k.o", ("HX_SP_VARIANT=v16k", "HX_SEG_DOCS=16384", "HX_SP_THREADS=1024")),
            ("spbuild.hip", "spbuild.o", ()), ("engine.hip", "engine.o", ()), ("bm25.cpp", "bm25.o", ())]
-HEADERS = ["hx_common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "hx.h")]
+HEADERS = ["hx_common.hpp", "kernels.hpp", "wsort.hpp", os.path.join("..", "..", "include", "hx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-function"]
 

@@ -3,6 +3,7 @@
 // descending order is (score desc, id asc) -- oracle/oracle.py order_key.
 #include "hx_common.hpp"
 #include "kernels.hpp"
+#include "wsort.hpp"
 
 namespace hx {
 
@@ -104,44 +105,6 @@ __global__ __launch_bounds__(NT) void k_compact(const uint64_t* __restrict__ key
 // of two descending runs is a bitonic run holding the best 256 of both, sorted again by
 // the last 8 stages.  One barrier per round instead of one per stage (66 at P = 2048).
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t k64max(uint64_t a, uint64_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint64_t k64min(uint64_t a, uint64_t b) { return a > b ? b : a; }
-// compare-exchange stage (k, j) of the descending bitonic network over i = lane * 4 + e
-template <int K, int J>
-__device__ __forceinline__ void w_cx(uint64_t (&v)[4], int lane) {
-  if constexpr (J < 4) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if ((e & J) == 0) {
-        const bool desc = K < 4 ? ((e & K) == 0) : (((lane * 4) & K) == 0);
-        const uint64_t mx = k64max(v[e], v[e ^ J]), mn = k64min(v[e], v[e ^ J]);
-        v[e] = desc ? mx : mn;
-        v[e ^ J] = desc ? mn : mx;
-      }
-    }
-  } else {
-    constexpr int LM = J >> 2;
-    const bool lower = (lane & LM) == 0;
-    const bool desc = ((lane * 4) & K) == 0;
-    const bool take_max = lower == desc;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)v[e], LM, 64);
-      v[e] = take_max ? k64max(v[e], y) : k64min(v[e], y);
-    }
-  }
-}
-template <int K, int J>
-__device__ __forceinline__ void w_merge(uint64_t (&v)[4], int lane) {
-  w_cx<K, J>(v, lane);
-  if constexpr (J > 1) w_merge<K, J / 2>(v, lane);
-}
-template <int K>
-__device__ __forceinline__ void w_sort(uint64_t (&v)[4], int lane) {
-  if constexpr (K > 2) w_sort<K / 2>(v, lane);
-  w_merge<K, K / 2>(v, lane);
-}
-
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_compact_top256(const uint64_t* __restrict__ keys, int stride,
                                                             const int* __restrict__ in_cnt, int keep,

@@ -39,6 +39,7 @@
 #include <type_traits>
 #include "hx_common.hpp"
 #include "kernels.hpp"
+#include "wsort.hpp"
 
 // Compiled twice (rag_application_amd/build.py): -DHX_SP_VARIANT=v8k -DHX_SEG_DOCS=8192
 // -DHX_SP_THREADS=512 and -DHX_SP_VARIANT=v16k -DHX_SEG_DOCS=16384 -DHX_SP_THREADS=1024.
@@ -142,6 +143,56 @@ __device__ __forceinline__ void sp_sort_truncate(uint64_t* cand, int limit, int 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's appends have left the core
   __syncthreads();                                   // ... and every other wave's; S.cnt settled
   const int n = S.cnt;
+  if (limit <= 256 && n <= SP_WAVES * 256) {         // block-uniform; the usual case
+    // every wave sorts 256 keys in registers (wsort.hpp), then log2(SP_WAVES) pairwise folds through
+    // the sort scratch keep the best 256: one barrier per fold instead of one per bitonic stage
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint64_t v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = w * 256 + e * 64 + lane;
+      v[e] = i < n ? sp_ld_key(cand + i) : 0ull;
+    }
+    if (n > w * 256) w_sort_loop(v, lane, 2);
+#pragma unroll
+    for (int s = 0; (1 << s) < SP_WAVES; ++s) {
+      const int m = (2 << s) - 1;
+      if ((w & m) == (1 << s)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S.sort[w * 256 + lane * 4 + e] = v[e];
+      }
+      lds_barrier();   // (the first one also orders every wave's loads of cand before wave 0's stores)
+      const int pw = w + (1 << s);
+      if ((w & m) == 0 && n > pw * 256) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = k64max(v[e], S.sort[pw * 256 + 255 - (lane * 4 + e)]);
+        w_sort_loop(v, lane, 256);
+      }
+    }
+    if (w == 0) {
+      const int keep = n < limit ? n : limit;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (lane * 4 + e < keep) sp_st_key(cand + lane * 4 + e, v[e]);
+      if (n >= limit) {
+        const int kr = limit - 1;
+        const uint64_t mine = (kr & 3) == 0 ? v[0] : ((kr & 3) == 1 ? v[1] : ((kr & 3) == 2 ? v[2] : v[3]));
+        const uint64_t kth = (uint64_t)__shfl((unsigned long long)mine, kr >> 2, 64);
+        if (lane == 0) {
+          S.tau = key_score(kth);
+          S.cnt = limit;
+        }
+      }
+    }
+    lds_barrier();     // every fold has read its partner's slice
+    if (w != 0) {      // acc back to zero: each wave but 0 wrote its slice exactly once
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S.sort[w * 256 + lane * 4 + e] = 0ull;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    return;
+  }
   int P = SP_THREADS;                                // sort size: next power of two >= n
   while (P < n) P <<= 1;
   for (int i = tid; i < P; i += SP_THREADS) S.sort[i] = i < n ? sp_ld_key(cand + i) : 0ull;

@@ -1,0 +1,83 @@
+// In-register bitonic sorting network of one wave: 256 64-bit keys, 4 per lane, index i = lane * 4 + e,
+// descending.  Strides below 4 are register swaps, the rest lane exchanges (no LDS traffic of its own, no
+// barrier).  Used by k_compact_top256 (select.hip) and the candidate cut of k_sparse_score (sparse.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace hx {
+
+__device__ __forceinline__ uint64_t k64max(uint64_t a, uint64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint64_t k64min(uint64_t a, uint64_t b) { return a > b ? b : a; }
+// compare-exchange stage (k, j) of the descending bitonic network over i = lane * 4 + e
+template <int K, int J>
+__device__ __forceinline__ void w_cx(uint64_t (&v)[4], int lane) {
+  if constexpr (J < 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if ((e & J) == 0) {
+        const bool desc = K < 4 ? ((e & K) == 0) : (((lane * 4) & K) == 0);
+        const uint64_t mx = k64max(v[e], v[e ^ J]), mn = k64min(v[e], v[e ^ J]);
+        v[e] = desc ? mx : mn;
+        v[e ^ J] = desc ? mn : mx;
+      }
+    }
+  } else {
+    constexpr int LM = J >> 2;
+    const bool lower = (lane & LM) == 0;
+    const bool desc = ((lane * 4) & K) == 0;
+    const bool take_max = lower == desc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)v[e], LM, 64);
+      v[e] = take_max ? k64max(v[e], y) : k64min(v[e], y);
+    }
+  }
+}
+template <int K, int J>
+__device__ __forceinline__ void w_merge(uint64_t (&v)[4], int lane) {
+  w_cx<K, J>(v, lane);
+  if constexpr (J > 1) w_merge<K, J / 2>(v, lane);
+}
+template <int K>
+__device__ __forceinline__ void w_sort(uint64_t (&v)[4], int lane) {
+  if constexpr (K > 2) w_sort<K / 2>(v, lane);
+  w_merge<K, K / 2>(v, lane);
+}
+
+// The same network as a rolled loop (k from k0: 2 = full sort, 256 = merge of a bitonic run): a few
+// dozen instructions and hardly any scalar registers, for use inside a kernel whose hot loop cannot
+// afford the register pressure of the unrolled form (k_sparse_score).
+__device__ __forceinline__ void w_sort_loop(uint64_t (&v)[4], int lane, int k0) {
+#pragma nounroll
+  for (int k = k0; k <= 256; k <<= 1) {
+#pragma nounroll
+    for (int j = k >> 1; j >= 4; j >>= 1) {
+      const int lm = j >> 2;
+      const bool take_max = ((lane & lm) == 0) == (((lane * 4) & k) == 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)v[e], lm, 64);
+        v[e] = take_max ? k64max(v[e], y) : k64min(v[e], y);
+      }
+    }
+    if (k >= 4) {   // j = 2: pairs (0, 2), (1, 3)
+      const bool desc = ((lane * 4) & k) == 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint64_t mx = k64max(v[e], v[e + 2]), mn = k64min(v[e], v[e + 2]);
+        v[e] = desc ? mx : mn;
+        v[e + 2] = desc ? mn : mx;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {   // j = 1: pairs (0, 1), (2, 3)
+      const bool desc = ((lane * 4 + e) & k) == 0;
+      const uint64_t mx = k64max(v[e], v[e + 1]), mn = k64min(v[e], v[e + 1]);
+      v[e] = desc ? mx : mn;
+      v[e + 1] = desc ? mn : mx;
+    }
+  }
+}
+
+}  // namespace hx
