@@ -351,6 +351,31 @@ __device__ __forceinline__ int sp_find_term(const SparseIndexView& ix, uint32_t 
   return (lo < ix.n_live && ix.uterms[lo] == term) ? lo : -1;
 }
 
+// The same lookup by one wave in 64-ary steps: ~log64(n_live) dependent loads instead of log2 (a
+// workgroup resolves its query's terms before it can start; `term` is wave-uniform).
+__device__ __forceinline__ int sp_find_term_wave(const SparseIndexView& ix, uint32_t term, int lane) {
+  int lo = 0, hi = ix.n_live;   // the first index whose term is >= `term` lies in [lo, hi]
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) >> 6;
+    const int p = lo + lane * step;
+    const bool in = p < hi;
+    const uint32_t v = in ? ix.uterms[p] : 0xFFFFFFFFu;
+    const int c = __popcll(__ballot(in && v < term));   // ascending list: a prefix of the probes
+    if (c == 0) {
+      hi = lo + 1;
+      break;
+    }
+    const int nhi = lo + c * step + 1;                  // probe c (if any) is >= term
+    lo = lo + (c - 1) * step + 1;                       // probe c - 1 is < term
+    hi = nhi < hi ? nhi : hi;
+  }
+  const int p = lo + lane;
+  const bool in = p < hi;
+  const uint32_t v = in ? ix.uterms[p] : 0xFFFFFFFFu;
+  const unsigned long long eq = __ballot(in && v == term);
+  return eq ? lo + (int)__builtin_ctzll(eq) : -1;
+}
+
 // chunks [c0, nch) of a segment by stride SP_WAVES, straight from memory (no prefetch):
 // accumulate (HARVEST = false) or exchange-harvest (HARVEST = true)
 template <bool HARVEST>
@@ -818,7 +843,10 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPE) __attribute__((amdgpu_num_vgpr(
     S.trig = 2 * a.limit < 256 ? 256 : 2 * a.limit;   // first cut early: it gives the first threshold
     S.tau = -__builtin_inff();
   }
-  for (int i = tid; i < T && i < SP_TCACHE; i += SP_THREADS) S.ti[i] = sp_find_term(a.ix, (uint32_t)a.q_idx[qb + i]);
+  for (int i = tid >> 6; i < T && i < SP_TCACHE; i += SP_WAVES) {   // one wave per term
+    const int r = sp_find_term_wave(a.ix, (uint32_t)a.q_idx[qb + i], tid & 63);
+    if ((tid & 63) == 0) S.ti[i] = r;
+  }
   __syncthreads();
   if (T <= SP_TG && T > 0 && s0 < s1) {   // block-uniform
 #if HX_SP_PP
