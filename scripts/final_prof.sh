@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-V=v10
+V=${1:-v11}
 timeout -k 10 300 python $R/bench.py > $R/gpurun_out/bench_$V.json 2> $R/gpurun_out/bench_$V.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$V -o $V -- python $R/bench.py --steps 5 --no-cpu-baseline > $R/gpurun_out/bench_${V}p.json 2> $R/gpurun_out/bench_${V}p.err
 for G in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
