@@ -68,6 +68,34 @@ def test_no_gpu_means_loud_failure_not_a_cpu_path(lib_path):
     assert "device" in str(e.value).lower()
 
 
+def test_argument_errors_are_reported_not_crashed(lib_path):
+    """Bad arguments fail with rc != 0 and a message before anything touches the device (so this runs
+    without a GPU): NULL pointers, limits outside [1, 2048], strides outside [1, 8192]."""
+    import ctypes as C
+    from rag_application_amd import _lib
+    lib = _lib.lib()
+    buf = (C.c_uint64 * 64)()
+    cnt = (C.c_int32 * 8)()
+    p, pc = C.addressof(buf), C.addressof(cnt)
+    cases = [
+        lambda: lib.hx_merge(0, None, 8, None, 1, 4, 0, p, pc, None),                 # NULL input
+        lambda: lib.hx_merge(0, p, 0, None, 1, 4, 0, p, pc, None),                    # stride 0
+        lambda: lib.hx_merge(0, p, 9000, None, 1, 4, 0, p, pc, None),                 # stride > 8192
+        lambda: lib.hx_merge(0, p, 8, None, 1, 4096, 0, p, pc, None),                 # limit > 2048
+        lambda: lib.hx_rrf(0, None, 4, pc, p, 4, pc, 1, 2.0, 0, 4, p, pc, None),      # NULL list
+        lambda: lib.hx_h1_fuse(0, None, 2, 1, 4, 4, 4, 2.0, 0, p, pc, None),          # NULL gathered block
+        lambda: lib.hx_h1_fuse(0, p, 0, 1, 4, 4, 4, 2.0, 0, p, pc, None),             # world 0
+        lambda: lib.hx_h1_fuse(0, p, 100, 1, 100, 100, 10, 2.0, 0, p, pc, None),      # world x limit > 8192
+        lambda: lib.hx_h1_fuse(0, p, 2, 1, 4, 4, 0, 2.0, 0, p, pc, None),             # limit 0
+        lambda: lib.hx_h1_local(None, p, p, p, p, 1, 4, 4, p, None),                  # NULL index
+        lambda: lib.hx_search_dense(None, p, 1, 0, 4, p, pc, None),
+        lambda: lib.hx_save(None, b"/tmp/x.hx"),
+    ]
+    for i, f in enumerate(cases):
+        assert f() != 0, f"case {i} did not fail"
+        assert lib.hx_last_error(), f"case {i}: no message"
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "rag_application_amd")
     for dp, _, files in os.walk(pkg):
