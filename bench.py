@@ -241,8 +241,9 @@ def main():
     if rank == 0:
         st = ix.stats()
         line = {
-            "metric": "queries/sec, 10M x 768 hybrid dense+BM25 (RRF top-10)" if args.workload == "cfg3"
-                      else f"queries/sec, {wl['desc']}",
+            "metric": "queries/sec, 10M x 768 hybrid dense+BM25 (RRF top-10)"
+                      if (args.workload == "cfg3" and rows == WORKLOADS["cfg3"]["rows"] and B == WORKLOADS["cfg3"]["batch"])
+                      else f"queries/sec, {wl['desc']} [rows={rows}, batch={B}]",
             "value": B * args.steps / dt, "unit": "queries/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
