@@ -55,12 +55,6 @@ namespace HX_SP_VARIANT {
 
 constexpr int SEG_DOCS = HX_SEG_DOCS;   // docs per index segment (LDS accumulator: 8 B per doc)
 constexpr int SP_CAND = SEG_DOCS;       // per-workgroup candidate buffer (keys, global memory)
-#ifndef HX_SP_PP
-#define HX_SP_PP 0
-#endif
-// HX_SP_PP = 1: two accumulators per workgroup, used by alternate visits, so that the harvest of
-// one visit runs beside the accumulation of the next and a visit has ONE barrier (sp_body_pipe_pp).
-constexpr int SP_ACC = HX_SP_PP ? 2 * SEG_DOCS : SEG_DOCS;
 
 // Diagnostic build only (-DHX_SP_STAMP): lane 0 of waves 0 and 3 accumulate s_memtime deltas per
 // phase into a debug buffer of its own (never read by the kernel, never in a timed build).
@@ -115,7 +109,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 struct SpShared {
   union {
-    unsigned long long acc[SP_ACC];          // marked fixed-point score per document of the segment
+    unsigned long long acc[SEG_DOCS];         // marked fixed-point score per document of the segment
     uint64_t sort[SEG_DOCS];                 // sort scratch while acc is all zero
   };
   int cnt;                                   // candidates in the workgroup's global buffer
@@ -380,8 +374,7 @@ __device__ __forceinline__ int sp_find_term_wave(const SparseIndexView& ix, uint
 // accumulate (HARVEST = false) or exchange-harvest (HARVEST = true)
 template <bool HARVEST>
 __device__ __forceinline__ void sp_chunks_direct(const SparseQueryArgs& a, const SpDir& d, float qw_lane, uint32_t c0,
-                                                 uint32_t nch, int lane, uint64_t* cand, float tau, int64_t gbase,
-                                                 uint32_t hoff = 0) {
+                                                 uint32_t nch, int lane, uint64_t* cand, float tau, int64_t gbase) {
   for (uint32_t c = c0; c < nch; c += SP_WAVES) {
     uint32_t off, cnt;
     float qw;
@@ -389,9 +382,9 @@ __device__ __forceinline__ void sp_chunks_direct(const SparseQueryArgs& a, const
     if ((uint32_t)lane < cnt) {
       const uint2 p = a.ix.post[off + lane];
       if (!HARVEST) {
-        atomicAdd(&S.acc[hoff + p.x], sp_fix(qw, __builtin_bit_cast(float, p.y)));
+        atomicAdd(&S.acc[p.x], sp_fix(qw, __builtin_bit_cast(float, p.y)));
       } else {
-        const unsigned long long x = atomicExch(&S.acc[hoff + p.x], 0ull);
+        const unsigned long long x = atomicExch(&S.acc[p.x], 0ull);
         if (x != 0ull) sp_append(cand, tau, x, gbase + p.x);
       }
     }
@@ -404,7 +397,7 @@ __device__ __forceinline__ void sp_chunks_direct(const SparseQueryArgs& a, const
 // One pipeline stage = everything a wave holds for one future visit.
 struct SpStage {
   float q[SP_K];            // query weight of the chunk's term
-  uint32_t valid;           // bit k: slot k holds a posting
+  uint32_t cnt[SP_K];       // scalar: postings in slot k (lane l holds one iff l < cnt[k])
   SpDir d;
   uint32_t nch, total;      // scalar: chunks / postings of the segment
 };
@@ -499,16 +492,14 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
   auto issue = [&](auto jc, SpStage& st, int sx) {
     constexpr int J = decltype(jc)::value;
     const uint2* pp[SP_K];
-    st.valid = 0;
 #pragma unroll
     for (int k = 0; k < SP_K; ++k) {
       const uint32_t c = (uint32_t)(k * SP_WAVES + wave);
       uint32_t off = 0, cnt = 0;
       st.q[k] = 0.f;
       if (c < st.nch) sp_chunk(st.d, qw_lane, c, off, cnt, st.q[k]);   // wave-uniform
-      const bool ok = (uint32_t)lane < cnt;
-      pp[k] = a.ix.post + off + (ok ? lane : 0);
-      st.valid |= (ok ? 1u : 0u) << k;
+      pp[k] = a.ix.post + off + ((uint32_t)lane < cnt ? lane : 0);
+      st.cnt[k] = cnt;
     }
     const uint32_t* pl = row + clampi(sx + SP_D);
     const uint32_t* ph = row + clampi(sx + SP_D + 1);
@@ -534,12 +525,11 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
   // The candidate count and the threshold live in LDS (S.cnt, S.tau); a visit works from scalar
   // copies: `ub` >= S.cnt (every posting of a visit could become a candidate) and `tau_r` <=
   // S.tau (a stale threshold only lets more candidates through).  They are refreshed where the
-  // buffer may have to be cut: the first visits (early cuts give the first threshold), every 8th
-  // visit, and whenever `ub` says the visit might not fit.
-  uint32_t npost_lane = 0;            // postings of this lane's term (rows 0 only count)
+  // buffer may have to be cut: the first 16 visits (early cuts give the first threshold), then every
+  // 8th, and whenever `ub` says the visit might not fit.
   uint32_t ub = 0;
   float tau_r = -__builtin_inff();
-  int nvis = 0;
+  int nvis = 0, next_chk = 0;         // non-empty visits so far / the one that refreshes ub and tau_r next
   SP_STAMP_DECL
 
   auto visit = [&](auto jc, SpStage& st, int seg) {
@@ -554,23 +544,25 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
     const int64_t gbase = a.ix.id_base + (int64_t)seg * SEG_DOCS;
     const uint32_t total = __builtin_amdgcn_readfirstlane(st.total), nch = __builtin_amdgcn_readfirstlane(st.nch);
     const SpDir d = st.d;
-    const uint32_t valid = st.valid;
+    uint32_t pc[SP_K];                                              // scalar; the refill below overwrites st
+#pragma unroll
+    for (int k = 0; k < SP_K; ++k) pc[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cnt[k]);
     const bool tails = nch > (uint32_t)(SP_K * SP_WAVES);          // scalar
     const uint32_t bound = total < (uint32_t)SEG_DOCS ? total : (uint32_t)SEG_DOCS;
     bool fast = true;
     if (total) {   // scalar
-      npost_lane += d.len;
-      if (nvis < 16 || (nvis & 7) == 0 || ub + bound > (uint32_t)SP_CAND) {   // scalar
+      if (nvis >= next_chk || ub + bound > (uint32_t)SP_CAND) {   // scalar
         sp_make_room(a, cand, total, tid);
         ub = (uint32_t)__builtin_amdgcn_readfirstlane(S.cnt);
         tau_r = S.tau;
+        next_chk = nvis + (nvis < 16 ? 1 : 8);
       }
       ++nvis;
       fast = ub + bound <= (uint32_t)SP_CAND;
       ub += bound;
 #pragma unroll
       for (int k = 0; k < SP_K; ++k)
-        if ((valid >> k) & 1u) atomicAdd(&S.acc[doc[k]], sp_fix(st.q[k], w[k]));
+        if ((uint32_t)lane < pc[k]) atomicAdd(&S.acc[doc[k]], sp_fix(st.q[k], w[k]));
       if (tails) sp_chunks_direct<false>(a, d, qw_lane, SP_K * SP_WAVES + wave, nch, lane, cand, 0.f, gbase);
     }
     SP_STAMP(1)
@@ -590,7 +582,7 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) {
           v[k] = 0ull;
-          if ((valid >> k) & 1u) v[k] = atomicExch(&S.acc[doc[k]], 0ull);
+          if ((uint32_t)lane < pc[k]) v[k] = atomicExch(&S.acc[doc[k]], 0ull);
         }
 #pragma unroll
         for (int k = 0; k < SP_K; ++k)
@@ -615,212 +607,12 @@ __device__ __forceinline__ void sp_body_pipe(const SparseQueryArgs& a, uint64_t*
   SP_STAMP_FLUSH
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
-  if (tid < 16 && a.stat_postings && npost_lane) atomicAdd(a.stat_postings, (unsigned long long)npost_lane);
+  if (tid < 16 && a.stat_postings && active) {   // postings of this lane's term in [s0, s1): adjacent runs
+    const uint32_t np = row[clampi(s1)] - row[clampi(s0)];
+    if (np) atomicAdd(a.stat_postings, (unsigned long long)np);
+  }
   sp_finish(a, cand, q, part, tid);
 }
-
-#if HX_SP_PP
-// ---------------------------------------------------------------------------------
-// pipelined path with two accumulators (HX_SP_PP): visit s accumulates into half s & 1 while the
-// previous visit -- the "pending" one -- is exchange-harvested from the other half:
-//     exchange(pending) ; accumulate(seg) ; derive + issue the loads of seg + 3 ; append(pending)
-//                                                                     -- barrier --
-// One barrier separates accumulate(s) from harvest(s) (next visit) and harvest(s - 1) from
-// accumulate(s + 1) (same half).  The two chains of a visit are independent, so the LDS round
-// trip of the exchange hides behind the fp64 conversion of the adds.
-// Buffer bookkeeping: S.cnt moves while waves append, so it is only read where no wave can be
-// appending: right after the barrier, and on those visits a second barrier keeps every append
-// behind every read.  A cut of the buffer (sort) or a visit that might not fit first drains the
-// pending harvest; the visit that might not fit then runs in the classic two-barrier form.
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ void sp_body_pipe_pp(const SparseQueryArgs& a, uint64_t* cand, unsigned long long* park, int q,
-                                                int part, int s0, int s1, int64_t qb, int T, int tid) {
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ts = lane & 15;
-  int ti = -1;
-  float qw_lane = 0.f;
-  if (ts < T) {
-    ti = S.ti[ts];
-    qw_lane = a.q_val[qb + ts];
-  }
-  const bool active = ti >= 0;
-  const uint32_t* row = a.ix.ptr + (int64_t)(active ? ti : 0) * (a.ix.n_segments + 1);
-  const int last = a.ix.n_segments;
-  auto clampi = [&](int x) __attribute__((always_inline)) { return x <= last ? x : last; };
-  auto issue = [&](auto jc, SpStage& st, int sx) __attribute__((always_inline)) {
-    constexpr int J = decltype(jc)::value;
-    const uint2* pp[SP_K];
-    st.valid = 0;
-#pragma unroll
-    for (int k = 0; k < SP_K; ++k) {
-      const uint32_t c = (uint32_t)(k * SP_WAVES + wave);
-      uint32_t off = 0, cnt = 0;
-      st.q[k] = 0.f;
-      if (c < st.nch) sp_chunk(st.d, qw_lane, c, off, cnt, st.q[k]);   // wave-uniform
-      const bool ok = (uint32_t)lane < cnt;
-      pp[k] = a.ix.post + off + (ok ? lane : 0);
-      st.valid |= (ok ? 1u : 0u) << k;
-    }
-    const uint32_t* pl = row + clampi(sx + SP_D);
-    const uint32_t* ph = row + clampi(sx + SP_D + 1);
-    if constexpr (J == 0) sp_stage_issue0(pl, ph, pp);
-    if constexpr (J == 1) sp_stage_issue1(pl, ph, pp);
-    if constexpr (J == 2) sp_stage_issue2(pl, ph, pp);
-  };
-  using J0 = std::integral_constant<int, 0>;
-  using J1 = std::integral_constant<int, 1>;
-  using J2 = std::integral_constant<int, 2>;
-
-  SpStage st0, st1, st2;
-  {
-    const uint32_t o0 = row[clampi(s0)], o1 = row[clampi(s0 + 1)], o2 = row[clampi(s0 + 2)], o3 = row[clampi(s0 + 3)];
-    st0.d = sp_dir<false>(o0, o1, active, st0.nch, st0.total);
-    st1.d = sp_dir<false>(o1, o2, active, st1.nch, st1.total);
-    st2.d = sp_dir<false>(o2, o3, active, st2.nch, st2.total);
-    issue(J0{}, st0, s0);
-    issue(J1{}, st1, s0 + 1);
-    issue(J2{}, st2, s0 + 2);
-  }
-  uint32_t npost_lane = 0;
-  uint32_t ub = 0;                    // >= S.cnt + everything the pending visit can append
-  float tau_r = -__builtin_inff();    // <= S.tau
-  int nvis = 0;
-  // the pending visit: accumulated into half p_hoff, not yet harvested
-  bool p_any = false;                 // scalar
-  uint32_t p_hoff = SEG_DOCS, p_nch = 0, p_bound = 0;   // scalar
-  int p_seg = 0;
-  uint32_t p_valid = 0, p_doc[SP_K];
-  SpDir p_d{};
-#pragma unroll
-  for (int k = 0; k < SP_K; ++k) p_doc[k] = 0;
-
-  auto harvest_pending = [&]() __attribute__((always_inline)) {   // drain (cold): exchange + append at once
-    if (!p_any) return;
-    const int64_t gbase = a.ix.id_base + (int64_t)p_seg * SEG_DOCS;
-#pragma unroll
-    for (int k = 0; k < SP_K; ++k) {
-      if ((p_valid >> k) & 1u) {
-        const unsigned long long x = atomicExch(&S.acc[p_hoff + p_doc[k]], 0ull);
-        if (x != 0ull) sp_append(cand, tau_r, x, gbase + p_doc[k]);
-      }
-    }
-    if (p_nch > (uint32_t)(SP_K * SP_WAVES))
-      sp_chunks_direct<true>(a, p_d, qw_lane, SP_K * SP_WAVES + wave, p_nch, lane, cand, tau_r, gbase, p_hoff);
-    p_any = false;
-    p_bound = 0;
-  };
-
-  auto visit = [&](auto jc, SpStage& st, int seg) __attribute__((always_inline)) {
-    constexpr int J = decltype(jc)::value;
-    uint32_t doc[SP_K], o_lo, o_hi;
-    float w[SP_K];
-    if constexpr (J == 0) sp_stage_collect0(doc, w, o_lo, o_hi);
-    if constexpr (J == 1) sp_stage_collect1(doc, w, o_lo, o_hi);
-    if constexpr (J == 2) sp_stage_collect2(doc, w, o_lo, o_hi);
-    const uint32_t total = __builtin_amdgcn_readfirstlane(st.total), nch = __builtin_amdgcn_readfirstlane(st.nch);
-    const SpDir d = st.d;
-    const uint32_t valid = st.valid;
-    float qk[SP_K];
-#pragma unroll
-    for (int k = 0; k < SP_K; ++k) qk[k] = st.q[k];
-    const bool tails = nch > (uint32_t)(SP_K * SP_WAVES);          // scalar
-    const uint32_t bound = total < (uint32_t)SEG_DOCS ? total : (uint32_t)SEG_DOCS;
-    uint32_t hoff = p_hoff ^ (uint32_t)SEG_DOCS;   // the half the pending visit does not use
-    bool bar = false;                              // appends of this visit wait for a second barrier
-    if (total) {   // scalar
-      npost_lane += d.len;
-      if (nvis < 16 || (nvis & 7) == 0 || ub + bound > (uint32_t)SP_CAND) {   // scalar
-        // no wave is appending here: the pending harvest starts below, behind `bar`
-        const int cnt = __builtin_amdgcn_readfirstlane(S.cnt);
-        const int trig = __builtin_amdgcn_readfirstlane(S.trig);
-        const bool over = (uint32_t)cnt + p_bound + bound > (uint32_t)SP_CAND;
-        if (over || (cnt > a.limit && cnt >= trig)) {
-          lds_barrier();              // every wave has read cnt
-          harvest_pending();
-          lds_barrier();              // both halves are zero
-          sp_make_room(a, cand, total, tid);
-          ub = (uint32_t)__builtin_amdgcn_readfirstlane(S.cnt);
-          tau_r = S.tau;
-          hoff = 0;
-          if (ub + bound > (uint32_t)SP_CAND) {
-            // classic form on half 0: accumulate, barrier, sweep-harvest (ends with a barrier)
-            ++nvis;
-#pragma unroll
-            for (int k = 0; k < SP_K; ++k)
-              if ((valid >> k) & 1u) atomicAdd(&S.acc[doc[k]], sp_fix(qk[k], w[k]));
-            if (tails) sp_chunks_direct<false>(a, d, qw_lane, SP_K * SP_WAVES + wave, nch, lane, cand, 0.f, 0, 0u);
-            st.d = sp_dir<false>(o_lo, o_hi, active, st.nch, st.total);
-            issue(jc, st, seg + SP_D);
-            lds_barrier();
-            sp_harvest(a, cand, park, seg, total, tid);
-            ub = (uint32_t)__builtin_amdgcn_readfirstlane(S.cnt);
-            tau_r = S.tau;
-            p_hoff = SEG_DOCS;
-            return;
-          }
-        } else {
-          ub = (uint32_t)cnt + p_bound;
-          tau_r = S.tau;
-          bar = p_any;
-        }
-      }
-      ++nvis;
-      ub += bound;
-    }
-    // exchange of the pending visit first: its round trip hides behind the adds
-    unsigned long long v[SP_K];
-#pragma unroll
-    for (int k = 0; k < SP_K; ++k) {
-      v[k] = 0ull;
-      if (p_any && ((p_valid >> k) & 1u)) v[k] = atomicExch(&S.acc[p_hoff + p_doc[k]], 0ull);
-    }
-    if (total) {
-#pragma unroll
-      for (int k = 0; k < SP_K; ++k)
-        if ((valid >> k) & 1u) atomicAdd(&S.acc[hoff + doc[k]], sp_fix(qk[k], w[k]));
-      if (tails) sp_chunks_direct<false>(a, d, qw_lane, SP_K * SP_WAVES + wave, nch, lane, cand, 0.f, 0, hoff);
-    }
-    st.d = sp_dir<false>(o_lo, o_hi, active, st.nch, st.total);
-    issue(jc, st, seg + SP_D);
-    if (bar) lds_barrier();
-    if (p_any) {
-      const int64_t gbase = a.ix.id_base + (int64_t)p_seg * SEG_DOCS;
-#pragma unroll
-      for (int k = 0; k < SP_K; ++k)
-        if (v[k] != 0ull) sp_append(cand, tau_r, v[k], gbase + p_doc[k]);
-      if (p_nch > (uint32_t)(SP_K * SP_WAVES))
-        sp_chunks_direct<true>(a, p_d, qw_lane, SP_K * SP_WAVES + wave, p_nch, lane, cand, tau_r, gbase, p_hoff);
-    }
-    // this visit becomes the pending one
-    p_any = total != 0;
-    p_bound = bound;
-    p_nch = nch;
-    p_seg = seg;
-    p_hoff = hoff;
-    p_valid = valid;
-    p_d = d;
-#pragma unroll
-    for (int k = 0; k < SP_K; ++k) p_doc[k] = doc[k];
-    lds_barrier();
-  };
-  int seg = s0;
-  for (;;) {
-    if (seg >= s1) break;
-    visit(J0{}, st0, seg);
-    if (++seg >= s1) break;
-    visit(J1{}, st1, seg);
-    if (++seg >= s1) break;
-    visit(J2{}, st2, seg);
-    ++seg;
-  }
-  harvest_pending();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  lds_barrier();
-  if (tid < 16 && a.stat_postings && npost_lane) atomicAdd(a.stat_postings, (unsigned long long)npost_lane);
-  sp_finish(a, cand, q, part, tid);
-}
-#endif   // HX_SP_PP
 
 // ---------------------------------------------------------------------------------
 // kernel: pipelined body for queries of up to 16 terms, grouped loop otherwise
@@ -837,7 +629,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPE) __attribute__((amdgpu_num_vgpr(
   unsigned long long* park = a.park + (int64_t)blockIdx.x * (SEG_DOCS / 2);
   static_assert(SP_CAND == SEG_DOCS, "the accumulator doubles as the sort scratch");
 
-  for (int i = tid; i < SP_ACC; i += SP_THREADS) S.acc[i] = 0;
+  for (int i = tid; i < SEG_DOCS; i += SP_THREADS) S.acc[i] = 0;
   if (tid == 0) {
     S.cnt = 0;
     S.trig = 2 * a.limit < 256 ? 256 : 2 * a.limit;   // first cut early: it gives the first threshold
@@ -849,11 +641,7 @@ __global__ __launch_bounds__(SP_THREADS, SP_WPE) __attribute__((amdgpu_num_vgpr(
   }
   __syncthreads();
   if (T <= SP_TG && T > 0 && s0 < s1) {   // block-uniform
-#if HX_SP_PP
-    sp_body_pipe_pp(a, cand, park, q, part, s0, s1, qb, T, tid);
-#else
     sp_body_pipe(a, cand, park, q, part, s0, s1, qb, T, tid);
-#endif
     return;
   }
   // grouped loop: 16 terms at a time, no prefetch
