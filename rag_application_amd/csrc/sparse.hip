@@ -147,7 +147,7 @@ __device__ __forceinline__ void sp_sort_truncate(uint64_t* cand, int limit, int 
       const int i = w * 256 + e * 64 + lane;
       v[e] = i < n ? sp_ld_key(cand + i) : 0ull;
     }
-    if (n > w * 256) w_sort_loop(v, lane, 2);
+    if (n > w * 256) w_sort<256>(v, lane);
 #pragma unroll
     for (int s = 0; (1 << s) < SP_WAVES; ++s) {
       const int m = (2 << s) - 1;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void sp_sort_truncate(uint64_t* cand, int limit, int 
       if ((w & m) == 0 && n > pw * 256) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = k64max(v[e], S.sort[pw * 256 + 255 - (lane * 4 + e)]);
-        w_sort_loop(v, lane, 256);
+        w_merge<256, 128>(v, lane);
       }
     }
     if (w == 0) {

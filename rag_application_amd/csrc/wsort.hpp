@@ -45,39 +45,4 @@ __device__ __forceinline__ void w_sort(uint64_t (&v)[4], int lane) {
   w_merge<K, K / 2>(v, lane);
 }
 
-// The same network as a rolled loop (k from k0: 2 = full sort, 256 = merge of a bitonic run): a few
-// dozen instructions and hardly any scalar registers, for use inside a kernel whose hot loop cannot
-// afford the register pressure of the unrolled form (k_sparse_score).
-__device__ __forceinline__ void w_sort_loop(uint64_t (&v)[4], int lane, int k0) {
-#pragma nounroll
-  for (int k = k0; k <= 256; k <<= 1) {
-#pragma nounroll
-    for (int j = k >> 1; j >= 4; j >>= 1) {
-      const int lm = j >> 2;
-      const bool take_max = ((lane & lm) == 0) == (((lane * 4) & k) == 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)v[e], lm, 64);
-        v[e] = take_max ? k64max(v[e], y) : k64min(v[e], y);
-      }
-    }
-    if (k >= 4) {   // j = 2: pairs (0, 2), (1, 3)
-      const bool desc = ((lane * 4) & k) == 0;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const uint64_t mx = k64max(v[e], v[e + 2]), mn = k64min(v[e], v[e + 2]);
-        v[e] = desc ? mx : mn;
-        v[e + 2] = desc ? mn : mx;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e += 2) {   // j = 1: pairs (0, 1), (2, 3)
-      const bool desc = ((lane * 4 + e) & k) == 0;
-      const uint64_t mx = k64max(v[e], v[e + 1]), mn = k64min(v[e], v[e + 1]);
-      v[e] = desc ? mx : mn;
-      v[e + 1] = desc ? mn : mx;
-    }
-  }
-}
-
 }  // namespace hx
