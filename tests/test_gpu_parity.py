@@ -676,19 +676,21 @@ def test_sparse_both_segment_sizes(eng, torch_mod, synth_tables, monkeypatch, se
     """The synthetic Zipf corpus through either sparse build: 60k documents, 300 queries, top-100."""
     from oracle import c_oracle as CO
     monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
-    n, B, L = 60000, 300, 100
+    n, B = 60000, 300
     ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
     ix = eng.HxIndex(64, ())
     ix.add(O.synth_dense(5, 0, n, 64), ip, si.astype(np.int32), sv)
     assert ix.stats()["n_segments"] in (0, (n + seg_docs - 1) // seg_docs)
     qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
-    es, ei, ec = CO.InvIndex(ip, si, sv).search(qip, qsi, qsv, L)
-    keys, cnt = ix.search_sparse(torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(),
-                                 torch_mod.from_numpy(qsv).cuda(), L)
-    assert ix.stats()["n_segments"] == (n + seg_docs - 1) // seg_docs
-    s, i, c = unpack_np(eng, keys, cnt)
-    for b in range(B):
-        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"sparse seg={seg_docs} b={b}")
+    inv = CO.InvIndex(ip, si, sv)
+    for L in (100, 10, 256, 257):    # <= 256: the in-register candidate cut; 257: the LDS sort
+        es, ei, ec = inv.search(qip, qsi, qsv, L)
+        keys, cnt = ix.search_sparse(torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(),
+                                     torch_mod.from_numpy(qsv).cuda(), L)
+        assert ix.stats()["n_segments"] == (n + seg_docs - 1) // seg_docs
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b in range(B):
+            assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"sparse seg={seg_docs} L={L} b={b}")
     ix.close()
 
 
