@@ -170,6 +170,18 @@ def main():
     dt = time.perf_counter() - t0
     prof = ix.profile_read()
     ix.profile(False)
+    # Rehearsal aid (HX_BENCH_VERIFY=1, N > 1, small --rows): rank 0 also builds the UNSHARDED corpus and
+    # checks the last step's lists against it, key for key.  Never part of the timed region.
+    verified = None
+    if world > 1 and mode == "h1" and os.environ.get("HX_BENCH_VERIFY"):
+        if rank == 0:
+            one = eng.HxIndex(dim, (64, 128, 256), device=local, id_base=0)
+            one.reserve(rows)
+            one.synth_fill(rows, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs)
+            k1, c1 = one.hybrid_query(Q, qip_d, qix_d, qv_d, hp)
+            verified = bool(torch.equal(k1, res[0]) and torch.equal(c1, res[1]))
+            one.close()
+        dist.barrier()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -252,7 +264,8 @@ def main():
                        "arithmetic": "fp16 MFMA candidate scan + exact fp32 re-score (certified); sparse: exact 2^40 "
                                      "fixed-point sums",
                        "sharding": f"rows/{world}", "nnz_per_shard": st["nnz"],
-                       "exact_fallback_queries": st["dense_fallback_queries"], "build_s": round(t_build, 2)},
+                       "exact_fallback_queries": st["dense_fallback_queries"], "build_s": round(t_build, 2),
+                       **({"sharded_equals_single_index": verified} if verified is not None else {})},
             "recall_at_10": cpu["recall_at_10"] if cpu else None,   # vs brute force on the cpu_baseline sample
             "roofline": roof, "cpu_baseline": cpu,
         }
