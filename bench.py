@@ -199,18 +199,18 @@ def main():
         # correction x2, MI355X_MICROARCH.md), kept under profiles/ -- counters cannot be read from
         # inside the timed process.  null when no pass for this configuration is committed.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_scan_v12.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_scan_v13.json")
         if world == 1 and os.path.exists(tpath):
             with open(tpath) as f:
                 tp = json.load(f)
             if tp.get("config") == {"rows": rows, "dim": dim, "batch": B, "n_gpus": 1}:
                 traffic = tp["scan_traffic_gb_per_step"] / max(sc["launches"] / args.steps, 1)
-        roof = dict(kernel="k_scan8<fp16, v_mfma_f32_16x16x32_f16> (256x256 tile; first chunk: k_scan)",
+        roof = dict(kernel="k_scan8<fp16, v_mfma_f32_16x16x32_f16> (256x256 tile)" if B > 128 else "k_scan<fp16> (128-row tiles)",
                     bound="mfma" if mfma_bound else "hbm",
                     achieved=tf if mfma_bound else gbs, peak=PEAK_FP16_TFLOPS if mfma_bound else PEAK_HBM_GBS,
                     unit="TFLOP/s" if mfma_bound else "GB/s",
                     frac=(tf / PEAK_FP16_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS), traffic=traffic,
-                    traffic_unit="GB per launch (profiles/r01_pmc_scan_v12.json)",
+                    traffic_unit="GB per launch (profiles/r01_pmc_scan_v13.json)",
                     launches=sc["launches"], avg_launch_ms=sc["ms"] / sc["launches"],
                     alg_tflop_per_launch=sc["flops"] / sc["launches"] / 1e12,
                     alg_gb_per_launch=sc["bytes"] / sc["launches"] / 1e9,
