@@ -259,6 +259,37 @@ def test_ties_and_certificate_fallback(eng, torch_mod):
         ix.close()
 
 
+def test_h1_fusion_redone_after_a_dense_retry(eng, torch_mod, synth_tables):
+    """In the H1 query the sparse stage and the fusion are enqueued BEFORE the host reads the dense
+    stage's failure flags; near-identical rows defeat the fp16 certificate, the exact path rewrites the
+    dense lists afterwards and the fusion has to be redone (engine.hip: search_dense `between`).  Same for
+    the sharded pair hx_h1_local / hx_h1_fuse."""
+    n, dim, B = 3000, 128, 9
+    base = O.synth_dense(11, 0, 40, dim)
+    X = (base[0][None, :] + O.synth_dense(12, 0, n, dim) * np.float32(1e-5)).astype(np.float32)
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    ora = O.OracleIndex(dim, ())
+    ora.add(X, ip, si, sv)
+    ora.finalize()
+    ix = eng.HxIndex(dim, ())
+    ix.add(X, ip, si.astype(np.int32), sv)
+    Q = O.synth_dense(13, 0, B, dim)
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(),
+          torch_mod.from_numpy(qsv).cuda())
+    hp = eng.make_params(dict(matryoshka_64_limit=1, matryoshka_128_limit=1, matryoshka_256_limit=1, dense_limit=60,
+                              quantized_limit=1, sparse_limit=50, final_limit=10, hnsw_ef=1), mode=eng.HX_MODE_H1)
+    s1, i1, c1 = unpack_np(eng, *ix.hybrid_query(Qd, *tq, hp))
+    assert ix.stats()["dense_fallback_queries"] > 0          # the retry really happened
+    s2, i2, c2 = unpack_np(eng, *eng.h1_fuse(ix.h1_local(Qd, *tq, 60, 50), 1, 60, 50, limit=10))
+    for b in range(B):
+        es, ei = O.hybrid_h1(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], 60, 50, 10)
+        assert_list_equal(s1[b], i1[b], c1[b], es, ei, f"h1 after retry b={b}")
+        assert_list_equal(s2[b], i2[b], c2[b], es, ei, f"h1_local/h1_fuse after retry b={b}")
+    ix.close()
+
+
 def test_overflow_retry_mixed_batch(eng, torch_mod):
     """Rows sorted so that scores RISE with the row id make every chunk append almost
     every row: candidate buffers overflow, the queries are retried with the safe
