@@ -81,6 +81,10 @@ int hx_reserve(hx_index* h, int64_t n_rows, int64_t nnz);
  * the L2-normalised "dense" vector, the normalised prefixes, the int8
  * "quantized" copy trunc(127*x) (qdrant_handler.py:144-150) and its norm. */
 int hx_add_dense(hx_index* h, const float* rows_host, int64_t n);
+/* the same for rows already on the device -- the output of an encoder on PyTorch-ROCm
+ * (embedding_handler.py:64-99 produces them; qdrant_handler.py:120-198 stores them): read in place,
+ * no staging copy.  Returns when the rows are stored. */
+int hx_add_dense_dev(hx_index* h, const float* rows_dev, int64_t n, void* stream);
 /* append the sparse vectors of the same n rows as doc-major CSR (host):
  * indptr[n+1], idx[nnz] (term ids in [0, 2^31)), val[nnz].  Indices must be
  * unique within a row (Qdrant rejects duplicates).  Rows must be added in the

@@ -52,6 +52,7 @@ _SIGS = {
     "hx_abi_version": [],
     "hx_reserve": [_P, C.c_int64, C.c_int64],
     "hx_add_dense": [_P, _P, C.c_int64],
+    "hx_add_dense_dev": [_P, _P, C.c_int64, _P],
     "hx_add_sparse": [_P, _P, _P, _P, C.c_int64],
     "hx_finalize": [_P],
     "hx_count": [_P, C.POINTER(C.c_int64)],

@@ -880,6 +880,27 @@ int hx_add_dense(hx_index* h, const float* rows_host, int64_t n) {
   HX_CATCH
 }
 
+int hx_add_dense_dev(hx_index* h, const float* rows_dev, int64_t n, void* stream) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  HX_CHECK(n >= 0, "n < 0");
+  if (n == 0) return 0;
+  HX_CHECK(rows_dev, "rows is NULL");
+  HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
+  h->set_device();
+  hipStream_t st = (hipStream_t)stream;
+  HX_HIP(hipStreamSynchronize(st));   // reserve_rows may move the stores; the caller's rows must be complete anyway
+  reserve_rows(h, h->n + n);
+  const int64_t CH = 65536;
+  for (int64_t r0 = 0; r0 < n; r0 += CH) {   // the encoder's output is read where it lies: no staging copy
+    const int64_t m = std::min(CH, n - r0);
+    prep_rows_device(h, rows_dev + r0 * h->dim, m, st);
+    h->n += m;
+  }
+  HX_HIP(hipStreamSynchronize(st));
+  HX_CATCH
+}
+
 int hx_add_sparse(hx_index* h, const int64_t* indptr, const int32_t* idx, const float* val, int64_t n) {
   HX_TRY
   HX_CHECK(h, "index is NULL");

@@ -119,6 +119,24 @@ class HxIndex:
         check(_lib.lib().hx_add_sparse(self._h, _ptr(sp_indptr), _ptr(sp_idx), _ptr(sp_val), n))
         check(_lib.lib().hx_add_dense(self._h, _ptr(dense), n))
 
+    def add_device(self, dense: torch.Tensor, sp_indptr=None, sp_idx=None, sp_val=None):
+        """`add` for dense rows that already live on the GPU (an encoder's output): hx_add_dense_dev."""
+        dense = _need_cuda(dense, torch.float32, "dense")
+        if dense.ndim != 2 or dense.shape[1] != self.dim:
+            raise ValueError(f"Dense vector dimension mismatch. Expected {self.dim}, got {dense.shape[-1]}")
+        n = dense.shape[0]
+        if sp_indptr is None:
+            sp_indptr = np.zeros(n + 1, dtype=np.int64)
+            sp_idx = np.zeros(0, dtype=np.int32)
+            sp_val = np.zeros(0, dtype=np.float32)
+        sp_indptr = np.ascontiguousarray(sp_indptr, dtype=np.int64)
+        sp_idx = np.ascontiguousarray(sp_idx, dtype=np.int32)
+        sp_val = np.ascontiguousarray(sp_val, dtype=np.float32)
+        if sp_indptr.shape[0] != n + 1:
+            raise ValueError("sparse indptr must have n+1 entries")
+        check(_lib.lib().hx_add_sparse(self._h, _ptr(sp_indptr), _ptr(sp_idx), _ptr(sp_val), n))
+        check(_lib.lib().hx_add_dense_dev(self._h, _ptr(dense), n, _stream()))
+
     def synth_fill(self, n: int, seed_dense: int, seed_sparse: int = 0, tables=None):
         if tables is not None:
             cdf = np.ascontiguousarray(tables[0], dtype=np.uint32)

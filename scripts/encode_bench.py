@@ -1,7 +1,7 @@
 """Side measurement for BASELINE config 5 (ingest), the "batched encode" leg: a bge-base-shaped BERT encoder
 (12 layers, hidden 768, 12 heads, FFN 3072, vocab 30522; RANDOMLY INITIALISED -- no checkpoint ships and none
 can be fetched) on PyTorch-ROCm, pooled the way the reference pools (UNMASKED mean of last_hidden_state,
-app/core/models/huggingface/huggingface.py:165-170), its output handed to the engine's ingest (hx_add_dense:
+app/core/models/huggingface/huggingface.py:165-170), its output handed to the engine's ingest (hx_add_dense_dev:
 normalise, prefixes, fp16 / int8 copies) on the same GPU.  chunks/s for token-id batches already on the
 device; tokenisation is host work outside this number.  argv: batch seq_len n_batches dtype(bf16|fp16|fp32)"""
 import os, sys, time, json
@@ -32,10 +32,10 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(NB):
     e = step()
 torch.cuda.synchronize(); t1 = time.perf_counter()
-# same, with the vectors appended to the index (device -> host -> hx_add_dense is the ABI's ingest entry today)
+# same, with the vectors appended to the index where they lie (hx_add_dense_dev)
 t2 = time.perf_counter()
 for _ in range(NB):
-    ix.add(step().cpu().numpy())
+    ix.add_device(step())
 torch.cuda.synchronize(); t3 = time.perf_counter()
 flops = 2.0 * B * S * (12 * (4 * 768 * 768 + 2 * 768 * 3072)) + 2.0 * 12 * B * 12 * S * S * 64 * 2
 print(json.dumps({"encoder": "BERT-base shape (bge-base), random init", "dtype": str(dt).split(".")[-1], "batch": B, "seq_len": S,

@@ -337,6 +337,29 @@ def test_small_and_empty(eng, torch_mod, synth_tables):
     ix2.close()
 
 
+def test_device_ingest_equals_host_ingest(eng, torch_mod, synth_tables):
+    """hx_add_dense_dev (rows already in HBM, as an encoder leaves them) stores exactly what hx_add_dense
+    stores: every derived copy compared bit for bit through hx_debug_row, plus a search."""
+    n, dim = 70000, 768     # more than one 65536-row ingest chunk
+    X = O.synth_dense(21, 0, n, dim) * np.float32(1.7)
+    a = eng.HxIndex(dim, (64, 128, 256))
+    a.add(X)
+    b = eng.HxIndex(dim, (64, 128, 256))
+    Xd = torch_mod.from_numpy(X).cuda()
+    b.add_device(Xd[:1000])
+    b.add_device(Xd[1000:])
+    assert a.count() == b.count() == n
+    for row in (0, 999, 1000, 65535, 65536, n - 1):
+        for which in (0, 1, 2, 3, 4):       # dense, the three prefixes, int8
+            np.testing.assert_array_equal(a.debug_row(which, row), b.debug_row(which, row), err_msg=f"{which} row {row}")
+    Q = torch_mod.from_numpy(O.synth_dense(22, 0, 40, dim)).cuda()
+    for ra, rb in ((a.search_dense(Q, 25), b.search_dense(Q, 25)), (a.search_dense(Q, 25, 64), b.search_dense(Q, 25, 64)),
+                   (a.search_i8(Q, 25), b.search_i8(Q, 25))):     # the fp16 copies and the int8 scales too
+        assert torch_mod.equal(ra[0], rb[0]) and torch_mod.equal(ra[1], rb[1])
+    a.close()
+    b.close()
+
+
 def test_synth_fill_matches_oracle(eng, torch_mod, synth_tables):
     n, dim = 20000, 768
     ix = eng.HxIndex(dim, (64, 128, 256))
