@@ -264,6 +264,8 @@ def main():
                        "arithmetic": "fp16 MFMA candidate scan + exact fp32 re-score (certified); sparse: exact 2^40 "
                                      "fixed-point sums",
                        "sharding": f"rows/{world}", "nnz_per_shard": st["nnz"],
+                       # N > 1: the exchange + fusion of batch i overlap the local stage of batch i + 1
+                       "batches_in_flight": 2 if pipe is not None else 1,
                        "exact_fallback_queries": st["dense_fallback_queries"], "build_s": round(t_build, 2),
                        **({"sharded_equals_single_index": verified} if verified is not None else {})},
             "recall_at_10": cpu["recall_at_10"] if cpu else None,   # vs brute force on the cpu_baseline sample
