@@ -133,6 +133,28 @@ class InvIndex:
             pass
 
 
+def set_sparse_fix_bits(bits) -> None:
+    """oracle.SPARSE_FIX_BITS for the C restatement: None = fp32 running sum in ascending term id."""
+    lib().ho_set_sparse_fix_bits(C.c_int(-1 if bits is None else int(bits)))
+
+
+def sparse_brute(indptr, idx, val, qip, qix, qv, L, id_base=0):
+    """Document-at-a-time sparse top-L straight from the doc-major CSR (ho_sparse_brute)."""
+    indptr = np.ascontiguousarray(indptr, np.int64)
+    idx = np.ascontiguousarray(idx, np.int32)
+    val = np.ascontiguousarray(val, F32)
+    qip = np.ascontiguousarray(qip, np.int64)
+    qix = np.ascontiguousarray(qix, np.int32)
+    qv = np.ascontiguousarray(qv, F32)
+    B = qip.shape[0] - 1
+    s = np.empty((B, L), F32)
+    i = np.empty((B, L), np.int64)
+    c = np.empty(B, np.int32)
+    lib().ho_sparse_brute(_p(indptr), _p(idx), _p(val), C.c_int64(indptr.shape[0] - 1), _p(qip), _p(qix), _p(qv),
+                          C.c_int(B), C.c_int(L), C.c_int64(id_base), _p(s), _p(i), _p(c))
+    return s, i, c
+
+
 def rrf(a, b, k=2.0, rank_base=0, limit=10):
     a = np.ascontiguousarray(a, np.int64)
     b = np.ascontiguousarray(b, np.int64)

@@ -328,25 +328,54 @@ static int64_t find_term(const ho_inv* iv, int32_t term) {
   return (lo < iv->n_terms && iv->terms[lo] == term) ? lo : -1;
 }
 
-/* score = f32(sum_t rint(f64(q_t)*f64(d_t)*2^40)) * 2^-40 : order-independent (oracle.py) */
+/* Sparse arithmetic switch (oracle.py SPARSE_FIX_BITS): < 0 = fp32 running sum over the query's terms in
+ * ascending term id (upstream's order, the default); k >= 0 = sum of rint(f64(q_t)*f64(d_t)*2^k) as int64,
+ * then f32(sum) * 2^-k (order-independent; round 1's engine arithmetic, kept as a switch). */
+static int g_fix_bits = -1;
+void ho_set_sparse_fix_bits(int bits) { g_fix_bits = bits; }
+int ho_get_sparse_fix_bits(void) { return g_fix_bits; }
+
+/* the query's terms of [qip[b], qip[b+1]) in ascending term id (stable): order[] holds positions */
+static void sorted_terms(const int32_t* qix, int64_t s, int64_t e, int64_t* order) {
+  const int64_t n = e - s;
+  for (int64_t i = 0; i < n; ++i) order[i] = s + i;
+  for (int64_t i = 1; i < n; ++i) {          /* insertion sort: a query has a handful of terms */
+    const int64_t v = order[i];
+    int64_t j = i;
+    while (j > 0 && qix[order[j - 1]] > qix[v]) { order[j] = order[j - 1]; --j; }
+    order[j] = v;
+  }
+}
+
+/* term-at-a-time over the inverted index (OracleIndex.sparse_scores) */
 void ho_search_sparse(const ho_inv* iv, const int64_t* qip, const int32_t* qix, const float* qv, int B,
                       int L, int64_t id_base, float* out_s, int64_t* out_i, int* out_c) {
+  const int fix = g_fix_bits;
+  const double scale = fix >= 0 ? ldexp(1.0, fix) : 0.0;
+  const float unscale = fix >= 0 ? (float)ldexp(1.0, -fix) : 0.0f;
+  int64_t tmax = 1;
+  for (int b = 0; b < B; ++b) if (qip[b + 1] - qip[b] > tmax) tmax = qip[b + 1] - qip[b];
 #pragma omp parallel
   {
     int64_t* acc = (int64_t*)calloc((size_t)(iv->n_docs + 1), 8);
+    float* accf = (float*)calloc((size_t)(iv->n_docs + 1), 4);
     uint8_t* seen = (uint8_t*)calloc((size_t)(iv->n_docs + 1), 1);
     int32_t* touched = (int32_t*)malloc((size_t)(iv->n_docs + 1) * 4);
     uint64_t* hk = (uint64_t*)malloc((size_t)(L > 0 ? L : 1) * 8);
+    int64_t* order = (int64_t*)malloc((size_t)tmax * 8);
 #pragma omp for schedule(dynamic, 1)
     for (int b = 0; b < B; ++b) {
       int64_t nt = 0;
-      for (int64_t j = qip[b]; j < qip[b + 1]; ++j) {
+      sorted_terms(qix, qip[b], qip[b + 1], order);
+      for (int64_t jj = 0; jj < qip[b + 1] - qip[b]; ++jj) {
+        const int64_t j = order[jj];
         const int64_t t = find_term(iv, qix[j]);
         if (t < 0) continue;
         const float qw = qv[j];
         for (int64_t i = iv->off[t]; i < iv->off[t + 1]; ++i) {
           const int32_t d = iv->doc[i];
-          acc[d] += (int64_t)nearbyint(((double)qw * (double)iv->w[i]) * 1099511627776.0);
+          if (fix >= 0) acc[d] += (int64_t)nearbyint(((double)qw * (double)iv->w[i]) * scale);
+          else accf[d] = accf[d] + qw * iv->w[i];      /* -ffp-contract=off: fp32 mul, fp32 add */
           if (!seen[d]) {
             seen[d] = 1;
             touched[nt++] = d;
@@ -356,14 +385,88 @@ void ho_search_sparse(const ho_inv* iv, const int64_t* qip, const int32_t* qix, 
       heap_t h = {hk, 0, L};
       for (int64_t i = 0; i < nt; ++i) {
         const int32_t d = touched[i];
-        heap_push(&h, make_key((float)acc[d] * 9.094947017729282e-13f, (uint32_t)(id_base + d)));
+        const float sc = fix >= 0 ? (float)acc[d] * unscale : accf[d];
+        heap_push(&h, make_key(sc, (uint32_t)(id_base + d)));
         acc[d] = 0;
+        accf[d] = 0.0f;
         seen[d] = 0;
       }
       emit_sorted(hk, h.n, L, out_s + (int64_t)b * L, out_i + (int64_t)b * L, out_c + b);
     }
-    free(acc); free(seen); free(touched); free(hk);
+    free(acc); free(accf); free(seen); free(touched); free(hk); free(order);
   }
+}
+
+/* The same scores document-at-a-time from the doc-major CSR, no inverted index: every document is
+ * intersected with every query (an independent second route to the same lists; bench.py uses it to
+ * brute-force a query sample over the whole corpus chunk by chunk).  Threads split the documents;
+ * each keeps a heap per query, merged at the end. */
+void ho_sparse_brute(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,
+                     const int64_t* qip, const int32_t* qix, const float* qv, int B, int L, int64_t id_base,
+                     float* out_s, int64_t* out_i, int* out_c) {
+  const int fix = g_fix_bits;
+  const double scale = fix >= 0 ? ldexp(1.0, fix) : 0.0;
+  const float unscale = fix >= 0 ? (float)ldexp(1.0, -fix) : 0.0f;
+  const int nt = n_threads();
+  const int Lh = L > 0 ? L : 1;
+  uint64_t* heaps = (uint64_t*)calloc((size_t)nt * B * Lh, 8);
+  int* hn = (int*)calloc((size_t)nt * B, 4);
+  int64_t nq = qip[B];
+  int64_t* order = (int64_t*)malloc((size_t)(nq + 1) * 8);
+  for (int b = 0; b < B; ++b) sorted_terms(qix, qip[b], qip[b + 1], order + qip[b]);
+  /* open-addressing set of every query term: most document terms are in no query */
+  int64_t cap = 64;
+  while (cap < 4 * (nq + 1)) cap <<= 1;
+  int32_t* hset = (int32_t*)malloc((size_t)cap * 4);
+  for (int64_t i = 0; i < cap; ++i) hset[i] = -1;
+  for (int64_t j = 0; j < nq; ++j) {
+    uint64_t p = ((uint64_t)(uint32_t)qix[j] * 0x9E3779B97F4A7C15ull) >> 20 & (uint64_t)(cap - 1);
+    while (hset[p] != -1 && hset[p] != qix[j]) p = (p + 1) & (uint64_t)(cap - 1);
+    hset[p] = qix[j];
+  }
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num();
+    int32_t hit_i[4096];
+    float hit_w[4096];
+#pragma omp for schedule(dynamic, 4096)
+    for (int64_t d = 0; d < n_docs; ++d) {
+      int nh = 0;
+      for (int64_t i = indptr[d]; i < indptr[d + 1] && nh < 4096; ++i) {
+        uint64_t p = ((uint64_t)(uint32_t)idx[i] * 0x9E3779B97F4A7C15ull) >> 20 & (uint64_t)(cap - 1);
+        while (hset[p] != -1 && hset[p] != idx[i]) p = (p + 1) & (uint64_t)(cap - 1);
+        if (hset[p] == idx[i]) { hit_i[nh] = idx[i]; hit_w[nh] = val[i]; ++nh; }
+      }
+      if (!nh) continue;
+      for (int b = 0; b < B; ++b) {
+        int64_t ai = 0;
+        float af = 0.0f;
+        int any = 0;
+        for (int64_t jj = qip[b]; jj < qip[b + 1]; ++jj) {      /* ascending term id */
+          const int64_t j = order[jj];
+          for (int k = 0; k < nh; ++k)
+            if (hit_i[k] == qix[j]) {
+              if (fix >= 0) ai += (int64_t)nearbyint(((double)qv[j] * (double)hit_w[k]) * scale);
+              else af = af + qv[j] * hit_w[k];
+              any = 1;
+              break;
+            }
+        }
+        if (!any) continue;
+        heap_t h = {heaps + ((size_t)t * B + b) * Lh, hn[(size_t)t * B + b], L};
+        heap_push(&h, make_key(fix >= 0 ? (float)ai * unscale : af, (uint32_t)(id_base + d)));
+        hn[(size_t)t * B + b] = h.n;
+      }
+    }
+  }
+  uint64_t* all = (uint64_t*)malloc((size_t)nt * Lh * 8);
+  for (int b = 0; b < B; ++b) {
+    int n = 0;
+    for (int t = 0; t < nt; ++t)
+      for (int i = 0; i < hn[(size_t)t * B + b]; ++i) all[n++] = heaps[((size_t)t * B + b) * Lh + i];
+    emit_sorted(all, n, L, out_s + (int64_t)b * L, out_i + (int64_t)b * L, out_c + b);
+  }
+  free(all); free(heaps); free(hn); free(order); free(hset);
 }
 
 /* ---- RRF ------------------------------------------------------------------------------ */

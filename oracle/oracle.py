@@ -21,9 +21,12 @@ upstream behaviour, unverifiable offline".
 Arithmetic contract (shared bit-for-bit with oracle/hx_oracle.c and the HIP
 engine; all fp32 operations are IEEE round-to-nearest, UNFUSED mul then add):
 
-sparse score        : sum over matching terms of rint(f64(q_t)*f64(d_t)*2^40) as int64,
-                      then f32(sum) * 2^-40 (order-independent restatement of upstream's
-                      fp32 running sum; differs from it by a few fp32 ulps at most).
+sparse score        : SPARSE_FIX_BITS = None (default, upstream order): the query's terms in
+                      ascending term id, acc = acc + q_t*d_t from +0 (fp32 mul, fp32 add) over the
+                      terms the document holds.  SPARSE_FIX_BITS = 40 (round-1 engine arithmetic,
+                      kept as a switch): sum of rint(f64(q_t)*f64(d_t)*2^40) as int64, then
+                      f32(sum) * 2^-40 -- order-independent, a few fp32 ulps from the former;
+                      tests/test_oracle.py measures how many lists differ between the two.
 ``spec_dot(x, q)``  : zero-pad to a multiple of 64; lane l (0..63) accumulates
                       p_l = p_l + x[64j+l]*q[64j+l] for j ascending from +0;
                       then p_l += p_{l+off} for off = 32,16,8,4,2,1 (l < off);
@@ -46,7 +49,9 @@ BM25_K = 1.2                   # fastembed Qdrant/bm25 defaults              (a-
 BM25_B = 0.75
 BM25_AVG_LEN = 256.0
 SPARSE_IDF = False             # collection has no sparse modifier           (a-1/a-6)
-SPARSE_FIX_BITS = 40           # sparse scores: order-independent fixed-point sum (see sparse_scores)
+SPARSE_FIX_BITS = None         # sparse scores: None = fp32 running sum in ascending term id (upstream's
+                               # order, the engine's arithmetic); 40 = the order-independent 2^40
+                               # fixed-point sum of round 1 (see sparse_scores)
 
 F32 = np.float32
 FLT_EPSILON = F32(1.1920929e-07)
@@ -273,18 +278,32 @@ class OracleIndex:
         s = ((dot.astype(F32) * self.q8_rinv) * rq).astype(F32)
         return topk(s, np.arange(self.n), limit)
 
-    def sparse_scores(self, q_idx, q_val):
+    def sparse_scores(self, q_idx, q_val, fix_bits="default"):
         """score(d) = sum over the query's terms of q_t * d_t; only docs sharing >= 1
-        term are candidates; IDF-free (a-6).  Each product is exact in fp64, scaled by
-        2^SPARSE_FIX_BITS and rounded (ties to even) to int64; the integer sum is converted once to
-        fp32 (so the result does not depend on the order of the terms).
+        term are candidates; IDF-free (a-6).
+        fix_bits None: the terms in ascending term id, acc = f32(acc + f32(q_t * d_t)) from +0 -- the
+        running sum of a term-at-a-time inverted-index search whose query indices are sorted (assumed
+        upstream behaviour).  fix_bits k: each product exact in fp64, scaled by 2^k, rounded (ties to
+        even) to int64; the integer sum is converted once to fp32 (order-independent).
         Returns (touched_doc_ids, scores)."""
+        fix_bits = SPARSE_FIX_BITS if fix_bits == "default" else fix_bits
         q_idx = np.asarray(q_idx, dtype=np.int64)
         q_val = np.asarray(q_val, dtype=F32)
-        acc = np.zeros(self.n, dtype=np.int64)
+        order = np.argsort(q_idx, kind="stable")
+        q_idx, q_val = q_idx[order], q_val[order]
         touched = np.zeros(self.n, dtype=bool)
         doc_of = np.repeat(np.arange(self.n), np.diff(self.sp_indptr))
-        scale = float(1 << SPARSE_FIX_BITS)
+        if fix_bits is None:
+            acc = np.zeros(self.n, dtype=F32)
+            for t, w in zip(q_idx, q_val):
+                m = self.sp_idx == t
+                d = doc_of[m]                    # a term occurs once per document: no duplicate d
+                acc[d] = (acc[d] + (F32(w) * self.sp_val[m]).astype(F32)).astype(F32)
+                touched[d] = True
+            ids = np.nonzero(touched)[0]
+            return ids, acc[ids]
+        acc = np.zeros(self.n, dtype=np.int64)
+        scale = float(1 << fix_bits)
         for t, w in zip(q_idx, q_val):
             m = self.sp_idx == t
             d = doc_of[m]
@@ -292,11 +311,11 @@ class OracleIndex:
             np.add.at(acc, d, fx)
             touched[d] = True
         ids = np.nonzero(touched)[0]
-        return ids, (acc[ids].astype(F32) * F32(2.0 ** -SPARSE_FIX_BITS)).astype(F32)
+        return ids, (acc[ids].astype(F32) * F32(2.0 ** -fix_bits)).astype(F32)
 
-    def search_sparse(self, q_idx, q_val, limit: int):
+    def search_sparse(self, q_idx, q_val, limit: int, fix_bits="default"):
         """Prefetch(query=SparseVector, using="sparse", limit) (qdrant_handler.py:347-354)."""
-        ids, s = self.sparse_scores(q_idx, q_val)
+        ids, s = self.sparse_scores(q_idx, q_val, fix_bits)
         return topk(s, ids, limit)
 
     # ---- candidate re-scoring (outer levels of a nested Prefetch) ----------
