@@ -32,6 +32,8 @@ WORKLOADS = {
 }
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
+SPARSE_ARITH = "exact 2^40 fixed-point sums"
+PMC_PROFILE = "r01_pmc_scan_v13.json"   # committed rocprofv3 --pmc pass the `traffic` figure is read from
 
 
 def parse():
@@ -43,50 +45,151 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override corpus rows (testing)")
     ap.add_argument("--batch", type=int, default=0, help="override query batch (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=4_000_000)
-    ap.add_argument("--cpu-queries", type=int, default=1024)
+    ap.add_argument("--cpu-queries", type=int, default=64,
+                    help="queries of the timed batch brute-forced on the host over the WHOLE corpus")
+    ap.add_argument("--no-secondary", action="store_true", help="skip tree mode / cfg2 / small-batch side measurements")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (box share per GPU)")
     return ap.parse_args()
 
 
-def cpu_baseline(wl, B, dim, tabs, cpu_rows, cpu_queries, gpu_check):
-    """The C restatement of the path (oracle/hx_oracle.c, kind "port") timed on this
-    box's host cores on a bounded sample: `cpu_queries` queries against the first
-    `cpu_rows` rows of the corpus.  Brute force is linear in rows, so the rate is scaled
-    by cpu_rows / rows.  Also returns the sample's exact lists for the parity gate."""
+CPU_BUILD = "gcc -O3 -mavx2 -fopenmp -ffp-contract=off (unfused fp32 mul + add: the arithmetic contract)"
+
+
+def _merge_best(best, s, i, c, L):
+    """Keep the best L (score desc, id asc) of the running per-query lists and a chunk's lists."""
+    from oracle import oracle as O
+    out = []
+    for b in range(len(best)):
+        ps, pi = best[b]
+        ns, ni = np.concatenate([ps, s[b, :c[b]]]), np.concatenate([pi, i[b, :c[b]]])
+        out.append(O.topk(ns, ni, L))
+    return out
+
+
+def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000):
+    """The C restatement of the path (oracle/hx_oracle.c, kind "port") timed on this box's host cores on a
+    bounded sample: the queries `sel` of the timed batch, brute force over the WHOLE corpus (regenerated
+    chunk by chunk, never resident at once).  The lists it produces are then compared -- ids and fp32 score
+    bits -- with what the TIMED GPU steps returned for those queries."""
     from oracle import c_oracle as CO
+    from oracle import oracle as O
     from rag_application_amd import synth
-    rows = wl["rows"]
-    ns = min(cpu_rows, rows)
-    bs = min(cpu_queries, B)
+    rows, mode = wl["rows"], wl["mode"]
+    bs = len(sel)
+    L = 100 if mode == "h1" else 10
     threads = CO.num_threads()
-    X = CO.synth_dense(synth.SEED_CORPUS, 0, ns, dim)
-    Xn = CO.cosine_preprocess(X)
-    del X
-    Q = CO.synth_dense(synth.SEED_QUERY, 0, bs, dim)
-    Qn = CO.cosine_preprocess(Q)
-    inv = None
-    if wl["mode"] == "h1":
-        ip, ix, v = CO.synth_sparse_docs(synth.SEED_SPDOC, 0, ns, tabs)
-        inv = CO.InvIndex(ip, ix, v)
-        qip, qix, qv = synth.sparse_queries(synth.SEED_SPQUERY, 0, bs, tabs)
+    Qall = CO.synth_dense(synth.SEED_QUERY, 0, int(sel.max()) + 1, dim)
+    Qn = CO.cosine_preprocess(Qall[sel])
+    if mode == "h1":
+        qip_a, qix_a, qv_a = synth.sparse_queries(synth.SEED_SPQUERY, 0, int(sel.max()) + 1, tabs)
+        qip = np.zeros(bs + 1, np.int64)
+        qix, qv = [], []
+        for k, b in enumerate(sel):
+            qix.append(qix_a[qip_a[b]:qip_a[b + 1]])
+            qv.append(qv_a[qip_a[b]:qip_a[b + 1]])
+            qip[k + 1] = qip[k] + len(qix[-1])
+        qix, qv = np.concatenate(qix).astype(np.int32), np.concatenate(qv).astype(np.float32)
+    empty = (np.zeros(0, np.float32), np.zeros(0, np.int64))
+    dbest, sbest = [empty] * bs, [empty] * bs
+    t_cpu = 0.0
+    for r0 in range(0, rows, chunk_rows):
+        n = min(chunk_rows, rows - r0)
+        Xn = CO.cosine_preprocess(CO.synth_dense(synth.SEED_CORPUS, r0, n, dim))
+        t0 = time.perf_counter()
+        s, i, c = CO.search_dense(Xn, Qn, L, id_base=r0)
+        t_cpu += time.perf_counter() - t0
+        del Xn
+        dbest = _merge_best(dbest, s, i, c, L)
+        if mode == "h1":
+            ip, ix, v = CO.synth_sparse_docs(synth.SEED_SPDOC, r0, n, tabs)
+            t0 = time.perf_counter()
+            s, i, c = CO.sparse_brute(ip, ix, v, qip, qix, qv, L, id_base=r0)
+            t_cpu += time.perf_counter() - t0
+            del ip, ix, v
+            sbest = _merge_best(sbest, s, i, c, L)
     t0 = time.perf_counter()
-    if wl["mode"] == "h1":
-        ds, di, dc = CO.search_dense(Xn, Qn, 100)
-        ss, si, sc = inv.search(qip, qix, qv, 100)
-        out = [CO.rrf(di[b, :dc[b]], si[b, :sc[b]], 2.0, 0, 10) for b in range(bs)]
+    if mode == "h1":
+        out = [CO.rrf(dbest[k][1], sbest[k][1], 2.0, 0, 10) for k in range(bs)]
     else:
-        ds, di, dc = CO.search_dense(Xn, Qn, 10)
-        out = [(ds[b, :dc[b]], di[b, :dc[b]]) for b in range(bs)]
-    dt = time.perf_counter() - t0
-    ok = None
-    recall = None
-    if gpu_check is not None:
-        ok, recall = gpu_check(ns, bs, out)
-    return dict(value=bs / dt * (ns / rows), unit="queries/sec", cores=threads, kind="port",
-                sample=f"{bs} of {B} queries x rows [0,{ns}) of {rows} ({dt:.2f} s of CPU work); "
-                       f"brute force is linear in rows, rate scaled by {ns}/{rows}",
-                parity_on_sample=ok, recall_at_10=recall)
+        out = dbest
+    t_cpu += time.perf_counter() - t0
+    # ---- the TIMED result against the brute force: ids and score bits, and recall@10
+    ok, hit, want = True, 0, 0
+    gs, gi, gc = res_keys
+    for k, b in enumerate(sel):
+        es, ei = out[k]
+        m = len(ei)
+        ok &= int(gc[b]) == m and np.array_equal(gi[b, :m], ei) and \
+            np.array_equal(gs[b, :m].view(np.uint32), np.asarray(es, np.float32).view(np.uint32))
+        hit += len(np.intersect1d(gi[b, :int(gc[b])], ei))
+        want += m
+    return dict(value=bs / t_cpu, unit="queries/sec", cores=threads, host_cores=os.cpu_count(), kind="port",
+                build=CPU_BUILD,
+                sample=f"{bs} of {wl['batch']} queries of the timed batch (every {wl['batch'] // bs}th) x ALL {rows} rows, "
+                       f"brute force chunk by chunk ({t_cpu:.2f} s of CPU search work, data generation not counted); "
+                       f"document-at-a-time sparse scoring; one timing, {threads} of {os.cpu_count()} host cores",
+                parity_on_sample=bool(ok), recall_at_10=(hit / want if want else None),
+                checked="ids and fp32 score bits of the LAST TIMED STEP's lists for the sampled queries")
+
+
+def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, steps=3):
+    """Side measurements on the driver record: the reference tree on the same index, the
+    bandwidth-bound dense kNN (B = 1 / 8 / 32) on the same corpus, and BASELINE config 2."""
+    out = {}
+    B = Q.shape[0]
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, r
+
+    if wl["mode"] == "h1":
+        dt, _ = timed(lambda: ix.hybrid_query(Q, *sp_q, hp_tree), steps)
+        out["tree_mode"] = dict(what="reference tree (qdrant_handler.py:305-372), P-mcp limits 100/80/60/40/40/50/30, "
+                                     "same index and batch", queries_per_sec=B / dt, ms_per_step=dt * 1e3)
+    runs = []
+    for b in (1, 8, 32):
+        q = Q[:b].contiguous()
+        for name, fn, key in (("fp16 scan + exact fp32 re-score", lambda: ix.search_dense(q, 10), "scan_f16"),
+                              ("int8 scan (exact)", lambda: ix.search_i8(q, 10), "scan_i8")):
+            fn()
+            torch.cuda.synchronize()
+            ix.profile(True)
+            ix.profile_read()
+            dt, _ = timed(fn, 5)
+            p = ix.profile_read()[key]
+            ix.profile(False)
+            if p["ms"] > 0:
+                gbs = p["bytes"] / p["ms"] / 1e6
+                runs.append(dict(batch=b, stage=name, ms_per_pass=dt * 1e3, scan_ms_per_pass=p["ms"] / 6,   # 1 + 5 calls
+                                 scan_gbs=gbs, frac_of_hbm_peak=gbs / PEAK_HBM_GBS, queries_per_sec=b / dt))
+    out["dense_knn_small_batch"] = dict(
+        what=f"dense kNN top-10 over the same {wl['rows']} x {wl['dim']} corpus, B queries per pass: algorithmic bytes "
+             "(rows * row_bytes + B * row_bytes) / HIP-event time of the scan launches; north-star target >= 0.70",
+        peak_gbs=PEAK_HBM_GBS, runs=runs)
+    # BASELINE config 2 on an index of its own (1M x 384, dense only, B = 256), checked against the C oracle
+    c2 = WORKLOADS["cfg2"]
+    ix2 = eng.HxIndex(c2["dim"], (64, 128, 256), device=local)
+    ix2.synth_fill(c2["rows"], synth.SEED_CORPUS)
+    Q2 = eng.synth_queries_dense(c2["dim"], 0, c2["batch"], synth.SEED_QUERY, device=local)
+    dt, (k2, n2) = timed(lambda: ix2.search_dense(Q2, 10), 10)
+    s2, i2 = eng.unpack(k2)
+    s2, i2, n2 = s2.cpu().numpy(), i2.cpu().numpy(), n2.cpu().numpy()
+    ix2.close()
+    from oracle import c_oracle as CO
+    sel = np.arange(0, c2["batch"], 4)
+    Xn = CO.cosine_preprocess(CO.synth_dense(synth.SEED_CORPUS, 0, c2["rows"], c2["dim"]))
+    Qn = CO.cosine_preprocess(CO.synth_dense(synth.SEED_QUERY, 0, c2["batch"], c2["dim"])[sel])
+    es, ei, ec = CO.search_dense(Xn, Qn, 10)
+    ok = all(int(n2[b]) == int(ec[k]) and np.array_equal(i2[b, :ec[k]], ei[k, :ec[k]]) and
+             np.array_equal(s2[b, :ec[k]].view(np.uint32), es[k, :ec[k]].view(np.uint32)) for k, b in enumerate(sel))
+    out["cfg2"] = dict(what=c2["desc"], queries_per_sec=c2["batch"] / dt, ms_per_step=dt * 1e3,
+                       parity_vs_brute_force=bool(ok), checked=f"{len(sel)} of {c2['batch']} queries x all rows, ids + score bits")
+    return out
 
 
 def main():
@@ -199,7 +302,7 @@ def main():
         # correction x2, MI355X_MICROARCH.md), kept under profiles/ -- counters cannot be read from
         # inside the timed process.  null when no pass for this configuration is committed.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_scan_v13.json")
+        tpath = os.path.join(ROOT, "profiles", PMC_PROFILE)
         if world == 1 and os.path.exists(tpath):
             with open(tpath) as f:
                 tp = json.load(f)
@@ -210,7 +313,7 @@ def main():
                     achieved=tf if mfma_bound else gbs, peak=PEAK_FP16_TFLOPS if mfma_bound else PEAK_HBM_GBS,
                     unit="TFLOP/s" if mfma_bound else "GB/s",
                     frac=(tf / PEAK_FP16_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS), traffic=traffic,
-                    traffic_unit="GB per launch (profiles/r01_pmc_scan_v13.json)",
+                    traffic_unit=f"GB per launch, from the committed PMC pass profiles/{PMC_PROFILE} (not measured in this run)",
                     launches=sc["launches"], avg_launch_ms=sc["ms"] / sc["launches"],
                     alg_tflop_per_launch=sc["flops"] / sc["launches"] / 1e12,
                     alg_gb_per_launch=sc["bytes"] / sc["launches"] / 1e9,
@@ -225,30 +328,20 @@ def main():
                                          avg_launch_ms=sp["ms"] / sp["launches"],
                                          note="8 B per posting visited; latency-bound today (DESIGN.md)")
 
-    # ---- CPU baseline + parity gate on the sample (rank 0, N = 1 only) ---------------------
+    # ---- CPU baseline + parity of the TIMED result (rank 0, N = 1 only) ------------------------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        def gpu_check(ns, bs, cpu_lists):
-            six = eng.HxIndex(dim, (64, 128, 256), device=local, id_base=0)
-            six.synth_fill(ns, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs)
-            if mode == "h1":
-                qs = qip_d[: bs + 1].clone()
-                nnz = int(qs[-1].item())
-                k, c = six.hybrid_query(Q[:bs], qs, qix_d[:nnz], qv_d[:nnz], hp)
-            else:
-                k, c = six.search_dense(Q[:bs], 10)
-            s, i = eng.unpack(k)
-            s, i, c = s.cpu().numpy(), i.cpu().numpy(), c.cpu().numpy()
-            six.close()
-            ok, hit, want = True, 0, 0
-            for b in range(bs):
-                es, ei = cpu_lists[b]
-                ok &= int(c[b]) == len(ei) and np.array_equal(i[b, :len(ei)], ei) and \
-                    np.array_equal(s[b, :len(ei)].view(np.uint32), np.asarray(es, np.float32).view(np.uint32))
-                hit += len(np.intersect1d(i[b, :int(c[b])], ei))      # recall@10 vs the brute-force lists
-                want += len(ei)
-            return bool(ok), (hit / want if want else None)
-        cpu = cpu_baseline(wl, B, dim, tabs, args.cpu_rows, args.cpu_queries, gpu_check)
+    side = None
+    if rank == 0 and world == 1:
+        if not args.no_secondary:
+            hp_tree = eng.make_params(P, mode=eng.HX_MODE_TREE)
+            side = secondary(eng, synth, torch, ix, wl, tabs, Q, (qip_d, qix_d, qv_d) if mode == "h1" else None,
+                             local, hp_tree)
+        if not args.no_cpu_baseline:
+            gs, gi = eng.unpack(res[0])
+            res_np = (gs.cpu().numpy(), gi.cpu().numpy(), res[1].cpu().numpy())
+            nq = max(1, min(args.cpu_queries, B))
+            sel = np.arange(0, B, max(B // nq, 1))[:nq]
+            cpu = cpu_baseline(wl, sel, dim, tabs, res_np)
 
     if rank == 0:
         st = ix.stats()
@@ -261,15 +354,16 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "rows": rows, "dim": dim, "batch": B, "top_k": 10,
-                       "arithmetic": "fp16 MFMA candidate scan + exact fp32 re-score (certified); sparse: exact 2^40 "
-                                     "fixed-point sums",
+                       "arithmetic": "dense: fp16 MFMA candidate scan + exact fp32 re-score (certified); sparse: "
+                                     + SPARSE_ARITH,
                        "sharding": f"rows/{world}", "nnz_per_shard": st["nnz"],
                        # N > 1: the exchange + fusion of batch i overlap the local stage of batch i + 1
                        "batches_in_flight": 2 if pipe is not None else 1,
                        "exact_fallback_queries": st["dense_fallback_queries"], "build_s": round(t_build, 2),
                        **({"sharded_equals_single_index": verified} if verified is not None else {})},
-            "recall_at_10": cpu["recall_at_10"] if cpu else None,   # vs brute force on the cpu_baseline sample
-            "roofline": roof, "cpu_baseline": cpu,
+            # recall@10 of the LAST TIMED STEP's lists against the host brute force over the whole corpus
+            "recall_at_10": cpu["recall_at_10"] if cpu else None,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": side,
         }
         print(json.dumps(line), flush=True)
     ix.close()

@@ -88,9 +88,18 @@ int hx_add_dense_dev(hx_index* h, const float* rows_dev, int64_t n, void* stream
 /* append the sparse vectors of the same n rows as doc-major CSR (host):
  * indptr[n+1], idx[nnz] (term ids in [0, 2^31)), val[nnz].  Indices must be
  * unique within a row (Qdrant rejects duplicates).  Rows must be added in the
- * same order as hx_add_dense; a row may be empty. */
+ * same order as hx_add_dense; a row may be empty.  Values must be finite with
+ * |v| <= 1e18 (anything else is refused, nothing is stored).  Sparse vectors are the
+ * vectors of the NEXT rows: call it BEFORE hx_add_dense of the same rows (rows that got
+ * no sparse vector earlier are padded as empty documents first; a second call before the
+ * dense rows of the first arrived is refused). */
 int hx_add_sparse(hx_index* h, const int64_t* indptr_host, const int32_t* idx_host,
                   const float* val_host, int64_t n);
+/* one chunk batch, dense and sparse together, all or nothing (store_document_vectors builds
+ * one PointStruct per chunk carrying both, qdrant_handler.py:152-188): indptr_host NULL = no
+ * sparse vectors.  A failure leaves the index exactly as it was. */
+int hx_add_rows(hx_index* h, const float* rows_host, const int64_t* indptr_host, const int32_t* idx_host,
+                const float* val_host, int64_t n);
 /* build the on-device inverted index over everything added so far; searches
  * call it implicitly when the index is stale. */
 int hx_finalize(hx_index* h);
@@ -208,11 +217,12 @@ typedef struct hx_stats {
   int64_t dense_fallback_queries;   /* queries whose certificate failed so far */
   int64_t i8_fallback_queries;
   int64_t retry_queries;            /* queries re-run with the safe geometry (overflow, underflow, certificate) */
+  int64_t sparse_fallback_queries;  /* sparse queries served document-at-a-time (non-positive weights, > 64 terms, overflow) */
 } hx_stats;
 int hx_get_stats(hx_index* h, hx_stats* out);
 /* HIP-event profile of the hot kernels, measured on the stream they run on.
  * Index 0 = fp16 scan (k_scan<F16>), 1 = int8 scan (k_scan<I8>), 2 = sparse scoring
- * (k_sparse_score).  flops/bytes are ALGORITHMIC: 2*B*rows*D and rows*row_bytes +
+ * (k_sparse_select: the pass over the inverted index; bytes = 8 per posting of the queries' terms).  flops/bytes are ALGORITHMIC: 2*B*rows*D and rows*row_bytes +
  * B*row_bytes per scan launch.  hx_profile_read drains what was recorded
  * since the last read (it synchronises the recorded events). */
 typedef struct hx_prof {

@@ -37,7 +37,7 @@ class HxStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_rows", "nnz", "n_segments", "n_groups", "hash_capacity", "bytes_dense_f32",
         "bytes_dense_f16", "bytes_i8", "bytes_prefix", "bytes_sparse",
-        "dense_fallback_queries", "i8_fallback_queries", "retry_queries")]
+        "dense_fallback_queries", "i8_fallback_queries", "retry_queries", "sparse_fallback_queries")]
 
 
 class HxProf(C.Structure):
@@ -54,6 +54,7 @@ _SIGS = {
     "hx_add_dense": [_P, _P, C.c_int64],
     "hx_add_dense_dev": [_P, _P, C.c_int64, _P],
     "hx_add_sparse": [_P, _P, _P, _P, C.c_int64],
+    "hx_add_rows": [_P, _P, _P, _P, _P, C.c_int64],
     "hx_finalize": [_P],
     "hx_count": [_P, C.POINTER(C.c_int64)],
     "hx_nnz": [_P, C.POINTER(C.c_int64)],

@@ -10,11 +10,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libhx.so")
-# (source, object, extra defines): sparse.hip is built for both segment sizes (kernels.hpp)
+# (source, object, extra defines): sparse2.hip is built for both segment sizes (kernels.hpp)
 SOURCES = [("scan.hip", "scan.o", ()), ("scan8.hip", "scan8.o", ()), ("select.hip", "select.o", ()),
            ("prep.hip", "prep.o", ()),
-           ("sparse.hip", "sparse_v8k.o", ("HX_SP_VARIANT=v8k", "HX_SEG_DOCS=8192", "HX_SP_THREADS=512")),
-           ("sparse.hip", "sparse_v16k.o", ("HX_SP_VARIANT=v16k", "HX_SEG_DOCS=16384", "HX_SP_THREADS=1024")),
+           ("sparse2.hip", "sparse2_v32k.o", ("HX_SP_VARIANT=v32k", "HX_SEG_DOCS=32768", "HX_SP_THREADS=512")),
+           ("sparse2.hip", "sparse2_v64k.o", ("HX_SP_VARIANT=v64k", "HX_SEG_DOCS=65536", "HX_SP_THREADS=1024")),
+           ("sprescore.hip", "sprescore.o", ()),
            ("spbuild.hip", "spbuild.o", ()), ("engine.hip", "engine.o", ()), ("bm25.cpp", "bm25.o", ())]
 HEADERS = ["hx_common.hpp", "kernels.hpp", "wsort.hpp", os.path.join("..", "..", "include", "hx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",

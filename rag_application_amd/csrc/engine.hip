@@ -52,7 +52,9 @@ enum WsSlot {
   WS_T_A, WS_T_ACNT, WS_T_B, WS_T_BCNT, WS_T_C, WS_T_CCNT, WS_T_D, WS_T_DCNT, WS_T_E, WS_T_ECNT,
   WS_T_F, WS_T_FCNT, WS_T_G, WS_T_GCNT, WS_H_QD, WS_H_QIP, WS_H_QIX, WS_H_QV, WS_H_OUT, WS_H_OCNT,
   WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT, WS_KEPT,
-  WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC
+  WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC,
+  WS_SP_TI0, WS_SP_TI1, WS_SP_QS, WS_SP_MARGIN, WS_SP_FLAG, WS_SP_WORK, WS_SP_FAIL, WS_SP_LIST, WS_SP_LCNT,
+  WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF
 };
 
 template <typename T>
@@ -87,11 +89,22 @@ struct hx_index {
   float* sp_val = nullptr;
   int64_t sp_rows = 0, sp_rows_cap = 0, nnz = 0, nnz_cap = 0;
   bool sparse_stale = false;
-  SparseBuildOut sp{};
-  int n_segments = 0;
-  int seg_docs = SEG_DOCS_SMALL;      // segment size of the built inverted index
-  int seg_docs_force = 0;             // HX_DEBUG_SEG_DOCS (tests): 8192 / 16384, 0 = by size
-  int64_t sp_docs_built = 0;
+  // Inverted index = an immutable BASE over documents [0, base.n_docs) plus a TAIL over the documents added
+  // since (rebuilt on every finalize from the tail's postings only); the base is rebuilt once the tail has
+  // grown to a quarter of it.  Both are searched by the same select kernel; the exact scores come from the
+  // document-major CSR, which covers every document.
+  struct SparseIx {
+    SparseBuildOut sp{};
+    int64_t doc0 = 0, n_docs = 0;
+    int n_segments = 0;
+    int seg_docs = SEG_DOCS_SMALL;
+  };
+  SparseIx sp_base, sp_tail;
+  int seg_docs_force = 0;             // HX_DEBUG_SEG_DOCS (tests): 32768 / 65536, 0 = by size
+  int64_t tail_min_force = -1;        // HX_DEBUG_TAIL_MIN (tests): documents a tail may hold before the base is rebuilt
+  float sp_wmin = 0.f, sp_wmax = 0.f; // range of the document weights (all finite: checked at ingest)
+  bool sp_have_w = false;
+  int64_t sparse_fallbacks = 0;       // queries served by the document-at-a-time path
   Workspace ws;
   int64_t dense_fallbacks = 0, i8_fallbacks = 0, retries = 0;
   float* q8_tile_max = nullptr;     // max of q8_rinv per 256-row tile: the int8 scan's column bound
@@ -109,9 +122,9 @@ struct hx_index {
 
 namespace hx {
 
-void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st) {
-  if (a.ix.seg_docs == SEG_DOCS_LARGE) v16k::launch_sparse_score_variant(a, st);
-  else v8k::launch_sparse_score_variant(a, st);
+void launch_sparse_select(const SparseSelectArgs& a, hipStream_t st) {
+  if (a.ix.seg_docs == SEG_DOCS_LARGE) v64k::launch_sparse_select_variant(a, st);
+  else v32k::launch_sparse_select_variant(a, st);
 }
 
 // ---------------------------------------------------------------------------------
@@ -167,18 +180,48 @@ static void prep_rows_device(hx_index* h, const float* raw_dev, int64_t n, hipSt
   launch_prep_rows(a, st);
 }
 
+static void free_sparse_ix(hx_index::SparseIx& x) {
+  if (x.sp.post) (void)hipFree(x.sp.post);
+  if (x.sp.ptr) (void)hipFree(x.sp.ptr);
+  if (x.sp.uterms) (void)hipFree(x.sp.uterms);
+  x = hx_index::SparseIx{};
+}
 static void free_sparse_index(hx_index* h) {
-  if (h->sp.post) (void)hipFree(h->sp.post);
-  if (h->sp.ptr) (void)hipFree(h->sp.ptr);
-  if (h->sp.uterms) (void)hipFree(h->sp.uterms);
-  h->sp = SparseBuildOut{};
-  h->n_segments = 0;
-  h->sp_docs_built = 0;
+  free_sparse_ix(h->sp_base);
+  free_sparse_ix(h->sp_tail);
+}
+
+// merge the range of val[from, to) (device) into the index's weight range; non-finite values are refused
+static void track_weights_dev(hx_index* h, const float* val, int64_t n, hipStream_t st) {
+  if (n <= 0) return;
+  uint32_t* mm = (uint32_t*)h->ws.get(WS_SP_MM, 16);
+  const uint32_t init[3] = {0xFFFFFFFFu, 0u, 0u};
+  HX_HIP(hipMemcpyAsync(mm, init, 12, hipMemcpyHostToDevice, st));
+  launch_minmax_f32(val, n, (float*)mm, st);
+  uint32_t got[3];
+  HX_HIP(hipMemcpyAsync(got, mm, 12, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  HX_CHECK(got[2] == 0, "sparse values must be finite");
+  if (got[0] > got[1]) return;
+  const float lo = orderable_f32(got[0]), hi = orderable_f32(got[1]);
+  h->sp_wmin = h->sp_have_w ? std::min(h->sp_wmin, lo) : lo;
+  h->sp_wmax = h->sp_have_w ? std::max(h->sp_wmax, hi) : hi;
+  h->sp_have_w = true;
+}
+
+static void build_ix(hx_index* h, hx_index::SparseIx& x, int64_t doc0, int64_t n_docs, int seg_docs, hipStream_t st) {
+  free_sparse_ix(x);
+  if (n_docs <= 0) return;
+  build_sparse_index(h->sp_indptr, h->sp_idx, h->sp_val, doc0, n_docs, seg_docs, &x.sp, st);
+  if (!x.sp.post) return;             // no posting in the range
+  x.doc0 = doc0;
+  x.n_docs = n_docs;
+  x.seg_docs = seg_docs;
+  x.n_segments = (int)((n_docs + seg_docs - 1) / seg_docs);
 }
 
 static void finalize(hx_index* h, hipStream_t st) {
   if (!h->sparse_stale) return;
-  free_sparse_index(h);
   if (h->nnz > 0) {
     // rows added without a sparse vector are empty documents
     const int64_t rows = std::max(h->sp_rows, h->n);
@@ -188,11 +231,21 @@ static void finalize(hx_index* h, hipStream_t st) {
       HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows + 1, tail.data(), tail.size() * 8, hipMemcpyHostToDevice));
       h->sp_rows = rows;
     }
-    // fewer, larger visits pay once a workgroup has enough segments to walk (kernels.hpp)
-    h->seg_docs = h->seg_docs_force ? h->seg_docs_force : (h->sp_rows >= 3000000 ? SEG_DOCS_LARGE : SEG_DOCS_SMALL);
-    build_sparse_index(h->sp_indptr, h->sp_idx, h->sp_val, h->sp_rows, h->nnz, h->seg_docs, &h->sp, st);
-    h->n_segments = (int)((h->sp_rows + h->seg_docs - 1) / h->seg_docs);
-    h->sp_docs_built = h->sp_rows;
+    const int64_t built = h->sp_base.n_docs;
+    const int64_t fresh = h->sp_rows - built;
+    const int64_t tail_max = h->tail_min_force >= 0 ? h->tail_min_force : std::max<int64_t>(built / 4, 1 << 18);
+    if (built == 0 || fresh > tail_max) {
+      // fewer, larger visits pay once a workgroup has enough segments to walk (kernels.hpp)
+      const int sd = h->seg_docs_force ? h->seg_docs_force : (h->sp_rows >= 3000000 ? SEG_DOCS_LARGE : SEG_DOCS_SMALL);
+      free_sparse_ix(h->sp_tail);
+      build_ix(h, h->sp_base, 0, h->sp_rows, sd, st);
+      if (!h->sp_base.sp.post) h->sp_base.n_docs = 0;
+    } else if (fresh > 0) {
+      // incremental upsert (qdrant_handler.py:190-193 upserts per document): only the tail is sorted
+      build_ix(h, h->sp_tail, built, fresh, h->seg_docs_force ? h->seg_docs_force : SEG_DOCS_SMALL, st);
+    }
+  } else {
+    free_sparse_index(h);
   }
   h->sparse_stale = false;
 }
@@ -600,52 +653,248 @@ static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* o
                        out_cnt, st);
 }
 
-static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
-                          int B, int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
+// keys a (query, part) may hand to the exact pass: the top-L plus the documents within the margin of the L-th
+// (2048 at least: with discrete BM25 weights hundreds of documents can tie at the L-th score of a 10M-row shard)
+static int sparse_lout(int L) { return std::max(2048, next_pow2(L + L / 2 + 64)); }
+
+static SparseIndexView view_of(const hx_index* h, const hx_index::SparseIx& x) {
+  SparseIndexView v{};
+  v.post = x.sp.post;
+  v.ptr = x.sp.ptr;
+  v.uterms = x.sp.uterms;
+  v.n_live = (int)x.sp.n_live;
+  v.n_docs = x.n_docs;
+  v.n_segments = x.n_segments;
+  v.seg_docs = x.seg_docs;
+  v.id_base = h->id_base + x.doc0;
+  return v;
+}
+static SparseCsr csr_of(const hx_index* h) {
+  SparseCsr d{};
+  d.indptr = h->sp_indptr;
+  d.idx = h->sp_idx;
+  d.val = h->sp_val;
+  d.n_docs = h->sp_rows;
+  d.id_base = h->id_base;
+  return d;
+}
+
+// K7: select (integer pass over the inverted index, base and tail) -> exact scores of the kept candidates
+// -> top-L.  Everything is enqueued; sparse_resolve() then reads the per-query flags and serves the flagged
+// queries document-at-a-time.
+static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
+                           int B, int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   finalize(h, st);
-  if (h->n_segments == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
-  const int slots = h->seg_docs == SEG_DOCS_LARGE ? 256 : 512;   // workgroups resident at once
-  int parts = (slots + B - 1) / B;
-  parts = std::min(parts, h->n_segments);
-  parts = std::min(parts, CAND_CAP / L);
-  parts = std::max(parts, 1);
-  uint64_t* pk = (uint64_t*)h->ws.get(WS_SP_PARTS, (size_t)B * parts * L * 8);
-  int* pc = (int*)h->ws.get(WS_SP_PCNT, (size_t)B * parts * 4);
-  SparseQueryArgs a{};
-  a.ix.post = h->sp.post;
-  a.ix.ptr = h->sp.ptr;
-  a.ix.uterms = h->sp.uterms;
-  a.ix.n_live = (int)h->sp.n_live;
-  a.ix.seg_docs = h->seg_docs;
-  a.ix.n_docs = h->sp_docs_built;
-  a.ix.n_segments = h->n_segments;
-  a.ix.id_base = h->id_base;
-  a.q_indptr = q_indptr;
-  a.q_idx = q_idx;
-  a.q_val = q_val;
-  a.B = B;
-  a.parts = parts;
-  a.limit = L;
-  a.out = pk;
-  a.out_cnt = pc;
-  a.cand = (uint64_t*)h->ws.get(WS_SP_CAND, (size_t)B * parts * h->seg_docs * 8);
-  a.park = (unsigned long long*)h->ws.get(WS_SP_PARK, (size_t)B * parts * (h->seg_docs / 2) * 8);
-  a.q_order = (int*)h->ws.get(WS_SP_ORDER, (size_t)B * 4);
-  a.stat_postings = nullptr;
+  Workspace& w = h->ws;
+  int* flag = (int*)w.get(WS_SP_FLAG, (size_t)B * 4);
+  int* fail = (int*)w.get(WS_SP_FAIL, (size_t)B * 4);
+  HX_HIP(hipMemsetAsync(flag, 0, (size_t)B * 4, st));
+  HX_HIP(hipMemsetAsync(fail, 0, (size_t)B * 4, st));
+  const hx_index::SparseIx* ixs[2] = {&h->sp_base, &h->sp_tail};
+  if (h->sp_base.n_segments == 0 && h->sp_tail.n_segments == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  const int lout = sparse_lout(L);
+  // ---- per-query preparation
+  SparsePrepArgs pa{};
+  pa.q_indptr = q_indptr;
+  pa.q_idx = q_idx;
+  pa.q_val = q_val;
+  pa.B = B;
+  for (int v = 0; v < 2; ++v) {
+    pa.ix[v] = view_of(h, *ixs[v]);
+    pa.q_ti[v] = (int32_t*)w.get(v == 0 ? WS_SP_TI0 : WS_SP_TI1, (size_t)B * SP_TMAX * 4);
+  }
+  pa.wmax = h->sp_wmax;
+  pa.index_nonpos = (h->sp_have_w && h->sp_wmin > 0.0f) ? 0 : 1;
+  pa.q_qs = (float*)w.get(WS_SP_QS, (size_t)B * SP_TMAX * 4);
+  pa.q_margin = (int*)w.get(WS_SP_MARGIN, (size_t)B * 4);
+  pa.q_flag = flag;
+  pa.q_work = (unsigned long long*)w.get(WS_SP_WORK, (size_t)B * 8);
+  pa.stat_postings = nullptr;
   if (h->prof) {
     if (!h->sp_counter) {
       HX_HIP(hipMalloc((void**)&h->sp_counter, 8));
       HX_HIP(hipMemset(h->sp_counter, 0, 8));
     }
-    a.stat_postings = h->sp_counter;
+    pa.stat_postings = h->sp_counter;
   }
+  launch_sparse_prep(pa, st);
+  int* order = nullptr;
+  if (B <= 4096) {
+    order = (int*)w.get(WS_SP_ORDER, (size_t)B * 4);
+    launch_sparse_order(pa.q_work, B, order, st);
+  }
+  // ---- select: parts of the base, then parts of the tail, side by side in one list buffer
+  int parts[2] = {0, 0};
+  for (int v = 0; v < 2; ++v) {
+    if (ixs[v]->n_segments == 0) continue;
+    const int slots = ixs[v]->seg_docs == SEG_DOCS_LARGE ? 256 : 512;   // workgroups resident at once
+    int p = v == 0 ? (slots + B - 1) / B : 1;
+    p = std::min(p, ixs[v]->n_segments);
+    p = std::min(p, std::max(1, CAND_CAP / lout - 1));
+    parts[v] = std::max(p, 1);
+  }
+  const int pt = parts[0] + parts[1];
+  HX_CHECK((int64_t)pt * lout <= CAND_CAP, "sparse: limit too large");
+  uint64_t* pk = (uint64_t*)w.get(WS_SP_PARTS, (size_t)B * pt * lout * 8);
+  int* pc = (int*)w.get(WS_SP_PCNT, (size_t)B * pt * 4);
   {
     ProfScope ps(h, st, 2, 0.0, 0.0);
-    launch_sparse_score(a, st);
+    for (int v = 0; v < 2; ++v) {
+      if (!parts[v]) continue;
+      SparseSelectArgs a{};
+      a.ix = pa.ix[v];
+      a.q_indptr = q_indptr;
+      a.q_ti = pa.q_ti[v];
+      a.q_qs = pa.q_qs;
+      a.q_margin = pa.q_margin;
+      a.q_flag = flag;
+      a.B = B;
+      a.parts = parts[v];
+      a.limit = L;
+      a.lout = lout;
+      a.out = pk;
+      a.out_cnt = pc;
+      a.parts_total = pt;
+      a.part0 = v == 0 ? 0 : parts[0];
+      a.cand = (uint64_t*)w.get(v == 0 ? WS_SP_CAND : WS_SP_PARK, (size_t)B * parts[v] * (ixs[v]->seg_docs / 4) * 8);
+      a.q_order = order;
+      a.q_fail = fail;
+      launch_sparse_select(a, st);
+    }
   }
-  launch_compact(pk, parts * L, nullptr, B, L, 0, out_keys, L, out_cnt, nullptr, parts * L, st);
+  // ---- one list per query (best integer scores first), its exact scores, the top-L
+  uint64_t* list = pk;
+  int* lcnt = pc;
+  if (pt > 1) {
+    uint64_t* packed = (uint64_t*)w.get(WS_SP_LIST, (size_t)B * pt * lout * 8);
+    lcnt = (int*)w.get(WS_SP_LCNT, (size_t)B * 4);
+    launch_sparse_pack(pk, pc, B, pt, lout, packed, lcnt, st);
+    list = pk;     // the sorted union goes back to the (now free) parts buffer, stride lout
+    launch_compact(packed, pt * lout, lcnt, B, lout, 0, list, lout, lcnt, nullptr, pt * lout, st);
+  }
+  SparseRescoreArgs ra{};
+  ra.d = csr_of(h);
+  ra.q_indptr = q_indptr;
+  ra.q_idx = q_idx;
+  ra.q_val = q_val;
+  ra.cand = list;
+  ra.cnt = lcnt;
+  ra.stride = lout;
+  ra.B = B;
+  ra.limit = L;
+  ra.q_margin = pa.q_margin;
+  ra.q_flag = flag;
+  ra.out = (uint64_t*)w.get(WS_SP_EXACT, (size_t)B * lout * 8);
+  ra.out_cnt = (int*)w.get(WS_SP_ECNT, (size_t)B * 4);
+  ra.q_fail = fail;
+  launch_sparse_rescore(ra, st);
+  launch_compact(ra.out, lout, ra.out_cnt, B, std::min(L, lout), 0, out_keys, L, out_cnt, nullptr, lout, st);
+}
+
+// Document-at-a-time path for the listed queries: every row through the exact arithmetic.  Rows are taken in
+// geometrically growing chunks; a chunk appends the keys that reach the query's threshold (the L-th best so far)
+// and the buffer is compacted to the best L after it -- the classic rule of chunked_scan.  A query whose buffer
+// overflows (more than 8192 - L documents tie at or beat its threshold inside one chunk) is redone with a slot
+// per row, 8192 - L rows at a time.
+static void sparse_exact_fallback(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
+                                  const std::vector<int>& sel_in, int L, uint64_t* out_keys, int* out_cnt,
+                                  hipStream_t st) {
+  if (sel_in.empty()) return;
+  const int C = CAND_CAP;
+  SparseRangeArgs ra{};
+  ra.d = csr_of(h);
+  ra.q_indptr = q_indptr;
+  ra.q_idx = q_idx;
+  ra.q_val = q_val;
+  ra.stride = C;
+  std::vector<int> sel = sel_in;
+  for (int pass = 0; pass < 2 && !sel.empty(); ++pass) {
+    const int nsel = (int)sel.size();
+    int* qsel = (int*)h->ws.get(WS_QSEL, (size_t)nsel * 4);
+    HX_HIP(hipMemcpyAsync(qsel, sel.data(), (size_t)nsel * 4, hipMemcpyHostToDevice, st));
+    uint64_t* buf = (uint64_t*)h->ws.get(WS_FB_KEYS, (size_t)nsel * C * 8);
+    int* cnt = (int*)h->ws.get(WS_FB_CNT, (size_t)nsel * 4);
+    int* incnt = (int*)h->ws.get(WS_FB_INCNT, (size_t)nsel * 4);
+    float* tau = (float*)h->ws.get(WS_SP_FTAU, (size_t)nsel * 4);
+    int* ovf = (int*)h->ws.get(WS_SP_FOVF, (size_t)nsel * 4);
+    HX_HIP(hipMemsetAsync(buf, 0, (size_t)nsel * C * 8, st));
+    HX_HIP(hipMemsetAsync(cnt, 0, (size_t)nsel * 4, st));
+    HX_HIP(hipMemsetAsync(ovf, 0, (size_t)nsel * 4, st));
+    ra.qsel = qsel;
+    ra.nsel = nsel;
+    ra.out = buf;
+    if (pass == 0) {
+      launch_fill_f32(tau, nsel, -std::numeric_limits<float>::infinity(), st);
+      ra.tau = tau;
+      ra.cnt = cnt;
+      ra.ovf = ovf;
+      int64_t r0 = 0, r1 = std::min<int64_t>(h->sp_rows, C - L);
+      while (r0 < h->sp_rows) {
+        ra.row_begin = r0;
+        ra.row_end = r1;
+        launch_sparse_range(ra, st);
+        launch_compact(buf, C, cnt, nsel, L, 0, buf, C, cnt, tau, C, st);
+        r0 = r1;
+        r1 = std::min<int64_t>(h->sp_rows, r1 * 2);
+      }
+    } else {
+      ra.tau = nullptr;
+      ra.slot0 = L;
+      const int64_t CH = C - L;
+      for (int64_t r0 = 0; r0 < h->sp_rows; r0 += CH) {
+        const int64_t r1 = std::min<int64_t>(h->sp_rows, r0 + CH);
+        ra.row_begin = r0;
+        ra.row_end = r1;
+        launch_sparse_range(ra, st);
+        launch_fill_i32(incnt, nsel, (int)(L + (r1 - r0)), st);
+        launch_compact(buf, C, incnt, nsel, L, 0, buf, C, cnt, nullptr, C, st);
+      }
+    }
+    std::vector<int> hovf((size_t)nsel, 0);
+    if (pass == 0) {
+      HX_HIP(hipMemcpyAsync(hovf.data(), ovf, (size_t)nsel * 4, hipMemcpyDeviceToHost, st));
+      HX_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<int> again;
+    for (int f = 0; f < nsel; ++f) {
+      if (hovf[(size_t)f]) {
+        again.push_back(sel[(size_t)f]);
+        continue;
+      }
+      HX_HIP(hipMemcpyAsync(out_keys + (int64_t)sel[f] * L, buf + (int64_t)f * C, (size_t)L * 8,
+                            hipMemcpyDeviceToDevice, st));
+      HX_HIP(hipMemcpyAsync(out_cnt + sel[f], cnt + f, 4, hipMemcpyDeviceToDevice, st));
+    }
+    sel.swap(again);
+  }
+}
+
+// Reads the flags of the last sparse_enqueue on this index (one host round trip) and serves the flagged
+// queries exactly.  Returns whether rows of out_keys were rewritten.
+static bool sparse_resolve(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val, int B,
+                           int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
+  if (h->sp_base.n_segments == 0 && h->sp_tail.n_segments == 0) return false;
+  std::vector<int> flag((size_t)B), fail((size_t)B);
+  HX_HIP(hipMemcpyAsync(flag.data(), h->ws.get(WS_SP_FLAG, (size_t)B * 4), (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipMemcpyAsync(fail.data(), h->ws.get(WS_SP_FAIL, (size_t)B * 4), (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  std::vector<int> sel;
+  for (int b = 0; b < B; ++b) {
+    HX_CHECK(flag[(size_t)b] != 2, "sparse query values must be finite");
+    if (flag[(size_t)b] || fail[(size_t)b]) sel.push_back(b);
+  }
+  if (sel.empty()) return false;
+  h->sparse_fallbacks += (int64_t)sel.size();
+  sparse_exact_fallback(h, q_indptr, q_idx, q_val, sel, L, out_keys, out_cnt, st);
+  return true;
+}
+
+static void search_sparse(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
+                          int B, int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
+  sparse_enqueue(h, q_indptr, q_idx, q_val, B, L, out_keys, out_cnt, st);
+  sparse_resolve(h, q_indptr, q_idx, q_val, B, L, out_keys, out_cnt, st);
 }
 
 static void rescore(hx_index* h, const float* q_dev, int B, int prefix, const uint64_t* cand, int cstride,
@@ -709,10 +958,11 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
           out_cnt, st, w);
     };
     const bool patched = search_dense(h, qd, B, 0, p->dense_limit, D, Dc, st, 0, [&]() {
-      search_sparse(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+      sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
       fuse();
     });
-    if (patched) fuse();
+    const bool sp_patched = sparse_resolve(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+    if (patched || sp_patched) fuse();
     return;
   }
   // --- matryoshka cascade (qdrant_handler.py:305-330)
@@ -825,6 +1075,7 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
     const int v = atoi(e);
     if (v == SEG_DOCS_SMALL || v == SEG_DOCS_LARGE) h->seg_docs_force = v;
   }
+  if (const char* e = getenv("HX_DEBUG_TAIL_MIN")) h->tail_min_force = atoll(e);   // tests: force / forbid a tail index
   if (const char* e = getenv("HX_DEBUG_SCAN8_LOGCAP")) {   // tests: force the log-overflow path
     const int v = atoi(e);
     if (v >= 1 && v <= SCAN8_LOGCAP) h->scan_logcap = v;
@@ -859,24 +1110,92 @@ int hx_reserve(hx_index* h, int64_t n_rows, int64_t nnz) {
   HX_CATCH
 }
 
-int hx_add_dense(hx_index* h, const float* rows_host, int64_t n) {
-  HX_TRY
-  HX_CHECK(h, "index is NULL");
+// ---- ingest (store_document_vectors -> upsert, qdrant_handler.py:120-198) -----------------------------
+static void add_dense_host(hx_index* h, const float* rows_host, int64_t n) {
   HX_CHECK(n >= 0, "n < 0");
-  if (n == 0) return 0;
+  if (n == 0) return;
   HX_CHECK(rows_host, "rows is NULL");
   HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
   h->set_device();
   reserve_rows(h, h->n + n);
   const int64_t CH = 65536;
   float* raw = (float*)h->ws.get(WS_RAW, (size_t)std::min(n, CH) * h->dim * 4);
-  for (int64_t r0 = 0; r0 < n; r0 += CH) {
-    const int64_t m = std::min(CH, n - r0);
-    HX_HIP(hipMemcpy(raw, rows_host + r0 * h->dim, (size_t)m * h->dim * 4, hipMemcpyHostToDevice));
-    prep_rows_device(h, raw, m, nullptr);
-    HX_HIP(hipStreamSynchronize(nullptr));
-    h->n += m;
+  const int64_t n_before = h->n;
+  try {
+    for (int64_t r0 = 0; r0 < n; r0 += CH) {
+      const int64_t m = std::min(CH, n - r0);
+      HX_HIP(hipMemcpy(raw, rows_host + r0 * h->dim, (size_t)m * h->dim * 4, hipMemcpyHostToDevice));
+      prep_rows_device(h, raw, m, nullptr);
+      HX_HIP(hipStreamSynchronize(nullptr));
+      h->n += m;
+    }
+  } catch (...) {
+    h->n = n_before;   // all or nothing
+    throw;
   }
+}
+
+// Largest |value| a sparse vector may hold: products q_t * d_t then stay far inside fp32.
+constexpr float SPARSE_ABS_MAX = 1.0e18f;
+
+// Sparse vectors of the NEXT n rows (paired with dense rows by position).  Validates everything on the
+// host before anything is committed: monotone indptr, term ids in [0, 2^31) and unique per vector, finite
+// values with |v| <= SPARSE_ABS_MAX.  Rows that were added without a sparse vector before are padded as
+// empty documents first, so a sparse vector can never attach to the wrong row.
+static void add_sparse_host(hx_index* h, const int64_t* indptr, const int32_t* idx, const float* val, int64_t n) {
+  HX_CHECK(n >= 0, "n < 0");
+  if (n == 0) return;
+  HX_CHECK(indptr, "indptr is NULL");
+  HX_CHECK(indptr[0] == 0, "indptr[0] must be 0");
+  const int64_t nnz = indptr[n];
+  HX_CHECK(nnz >= 0, "negative nnz");
+  HX_CHECK(nnz == 0 || (idx && val), "idx/val is NULL");
+  HX_CHECK(h->sp_rows <= h->n, "sparse rows are ahead of the dense rows: add the dense rows of the previous batch first");
+  std::vector<int32_t> tmp;
+  float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t b = indptr[r], e = indptr[r + 1];
+    HX_CHECK(e >= b && e <= nnz, "indptr not monotone");
+    tmp.assign(idx + b, idx + e);
+    std::sort(tmp.begin(), tmp.end());
+    for (size_t i = 0; i < tmp.size(); ++i) {
+      HX_CHECK(tmp[i] >= 0, "sparse index out of range [0, 2^31)");
+      HX_CHECK(i == 0 || tmp[i] != tmp[i - 1], "sparse indices must be unique within a vector");
+    }
+    for (int64_t i = b; i < e; ++i) {
+      HX_CHECK(std::fabs(val[i]) <= SPARSE_ABS_MAX, "sparse values must be finite and at most 1e18 in magnitude");
+      lo = std::min(lo, val[i]);
+      hi = std::max(hi, val[i]);
+    }
+  }
+  h->set_device();
+  HX_CHECK(h->nnz + nnz < 0xFFFFFFFFll, "nnz per shard must stay below 2^32");
+  const int64_t pad = h->n - h->sp_rows;      // dense-only rows so far: empty documents
+  reserve_sparse(h, h->sp_rows + pad + n, h->nnz + nnz);
+  std::vector<int64_t> ip((size_t)(pad + n));
+  for (int64_t r = 0; r < pad; ++r) ip[(size_t)r] = h->nnz;
+  for (int64_t r = 0; r < n; ++r) ip[(size_t)(pad + r)] = h->nnz + indptr[r + 1];
+  if (h->sp_rows == 0) {
+    const int64_t zero = 0;
+    HX_HIP(hipMemcpy(h->sp_indptr, &zero, 8, hipMemcpyHostToDevice));
+  }
+  HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows + 1, ip.data(), ip.size() * 8, hipMemcpyHostToDevice));
+  if (nnz) {
+    HX_HIP(hipMemcpy(h->sp_idx + h->nnz, idx, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    HX_HIP(hipMemcpy(h->sp_val + h->nnz, val, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    h->sp_wmin = h->sp_have_w ? std::min(h->sp_wmin, lo) : lo;
+    h->sp_wmax = h->sp_have_w ? std::max(h->sp_wmax, hi) : hi;
+    h->sp_have_w = true;
+  }
+  h->sp_rows += pad + n;
+  h->nnz += nnz;
+  h->sparse_stale = true;
+}
+
+int hx_add_dense(hx_index* h, const float* rows_host, int64_t n) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  add_dense_host(h, rows_host, n);
   HX_CATCH
 }
 
@@ -904,41 +1223,34 @@ int hx_add_dense_dev(hx_index* h, const float* rows_dev, int64_t n, void* stream
 int hx_add_sparse(hx_index* h, const int64_t* indptr, const int32_t* idx, const float* val, int64_t n) {
   HX_TRY
   HX_CHECK(h, "index is NULL");
+  add_sparse_host(h, indptr, idx, val, n);
+  HX_CATCH
+}
+
+int hx_add_rows(hx_index* h, const float* rows_host, const int64_t* indptr, const int32_t* idx, const float* val,
+                int64_t n) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
   HX_CHECK(n >= 0, "n < 0");
   if (n == 0) return 0;
-  HX_CHECK(indptr, "indptr is NULL");
-  HX_CHECK(indptr[0] == 0, "indptr[0] must be 0");
-  const int64_t nnz = indptr[n];
-  HX_CHECK(nnz >= 0, "negative nnz");
-  HX_CHECK(nnz == 0 || (idx && val), "idx/val is NULL");
-  std::vector<int32_t> tmp;
-  for (int64_t r = 0; r < n; ++r) {
-    const int64_t b = indptr[r], e = indptr[r + 1];
-    HX_CHECK(e >= b && e <= nnz, "indptr not monotone");
-    tmp.assign(idx + b, idx + e);
-    std::sort(tmp.begin(), tmp.end());
-    for (size_t i = 0; i < tmp.size(); ++i) {
-      HX_CHECK(tmp[i] >= 0, "sparse index out of range [0, 2^31)");
-      HX_CHECK(i == 0 || tmp[i] != tmp[i - 1], "sparse indices must be unique within a vector");
-    }
+  HX_CHECK(rows_host, "rows is NULL");
+  HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
+  // a chunk's dense and sparse vectors are committed together: a failure of either leaves the index as it was
+  const int64_t sp_rows0 = h->sp_rows, nnz0 = h->nnz;
+  const bool stale0 = h->sparse_stale, have0 = h->sp_have_w;
+  const float lo0 = h->sp_wmin, hi0 = h->sp_wmax;
+  if (indptr) add_sparse_host(h, indptr, idx, val, n);
+  try {
+    add_dense_host(h, rows_host, n);
+  } catch (...) {
+    h->sp_rows = sp_rows0;
+    h->nnz = nnz0;
+    h->sparse_stale = stale0;
+    h->sp_have_w = have0;
+    h->sp_wmin = lo0;
+    h->sp_wmax = hi0;
+    throw;
   }
-  h->set_device();
-  HX_CHECK(h->nnz + nnz < 0xFFFFFFFFll, "nnz per shard must stay below 2^32");
-  reserve_sparse(h, h->sp_rows + n, h->nnz + nnz);
-  std::vector<int64_t> ip((size_t)n);
-  for (int64_t r = 0; r < n; ++r) ip[(size_t)r] = h->nnz + indptr[r + 1];
-  if (h->sp_rows == 0) {
-    const int64_t zero = 0;
-    HX_HIP(hipMemcpy(h->sp_indptr, &zero, 8, hipMemcpyHostToDevice));
-  }
-  HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows + 1, ip.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-  if (nnz) {
-    HX_HIP(hipMemcpy(h->sp_idx + h->nnz, idx, (size_t)nnz * 4, hipMemcpyHostToDevice));
-    HX_HIP(hipMemcpy(h->sp_val + h->nnz, val, (size_t)nnz * 4, hipMemcpyHostToDevice));
-  }
-  h->sp_rows += n;
-  h->nnz += nnz;
-  h->sparse_stale = true;
   HX_CATCH
 }
 
@@ -997,6 +1309,7 @@ int hx_synth_fill(hx_index* h, int64_t n, uint32_t seed_dense, uint32_t seed_spa
     HX_HIP(hipMemcpy(hip_.data(), ip, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
     for (auto& v : hip_) v += h->nnz;
     HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows, hip_.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+    track_weights_dev(h, h->sp_val + h->nnz, add, st);
     h->sp_rows += n;
     h->nnz += add;
     h->sparse_stale = true;
@@ -1110,10 +1423,11 @@ int hx_h1_local(hx_index* h, const float* qd, const int64_t* qip, const int32_t*
   auto pack = [&]() { launch_concat(D, dense_limit, Dc, S, sparse_limit, Sc, B, keys_dev, st); };
   // as in hybrid_query_dev: sparse + packing are enqueued before the host reads the dense flags
   const bool patched = search_dense(h, qd, B, 0, dense_limit, D, Dc, st, 0, [&]() {
-    search_sparse(h, qip, qix, qv, B, sparse_limit, S, Sc, st);
+    sparse_enqueue(h, qip, qix, qv, B, sparse_limit, S, Sc, st);
     pack();
   });
-  if (patched) pack();
+  const bool sp_patched = sparse_resolve(h, qip, qix, qv, B, sparse_limit, S, Sc, st);
+  if (patched || sp_patched) pack();
   HX_CATCH
 }
 
@@ -1220,9 +1534,9 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   std::memset(out, 0, sizeof(*out));
   out->n_rows = h->n;
   out->nnz = h->nnz;
-  out->n_segments = h->n_segments;
-  out->n_groups = h->sp.n_live;              // live terms
-  out->hash_capacity = h->sp.ptr_entries;    // entries of the term x segment offset table
+  out->n_segments = h->sp_base.n_segments + h->sp_tail.n_segments;
+  out->n_groups = h->sp_base.sp.n_live + h->sp_tail.sp.n_live;                  // live terms
+  out->hash_capacity = h->sp_base.sp.ptr_entries + h->sp_tail.sp.ptr_entries;   // entries of the term x segment offset tables
   out->bytes_dense_f32 = h->n * h->dim_pad * 4;
   out->bytes_dense_f16 = h->n * h->dim_pad * 2;
   out->bytes_i8 = h->n * h->dim_pad8;
@@ -1230,10 +1544,11 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   for (int p = 0; p < h->n_pre; ++p) bp += h->n * h->psize[p] * 4;
   if (h->n_pre) bp += h->n * h->psize[0] * 2;
   out->bytes_prefix = bp;
-  out->bytes_sparse = h->nnz * 8 + h->sp.ptr_entries * 4 + h->sp.n_live * 4;
+  out->bytes_sparse = h->nnz * 8 + out->hash_capacity * 4 + out->n_groups * 4;
   out->dense_fallback_queries = h->dense_fallbacks;
   out->i8_fallback_queries = h->i8_fallbacks;
   out->retry_queries = h->retries;
+  out->sparse_fallback_queries = h->sparse_fallbacks;
   HX_CATCH
 }
 
@@ -1365,7 +1680,27 @@ int hx_load(const char* path, int32_t device, hx_index** out) {
   HxFileHeader hd{};
   HX_CHECK(fread(&hd, sizeof hd, 1, fl.f) == 1, "short read: not an index file");
   HX_CHECK(memcmp(hd.magic, HX_MAGIC, 8) == 0, "not an hx index file (bad magic / version)");
+  // The header is not trusted: every size is checked against the limits of the add path and against the
+  // length of the file BEFORE anything is allocated (a corrupt count must not become a huge hipMalloc).
   HX_CHECK(hd.n >= 0 && hd.sp_rows >= 0 && hd.nnz >= 0 && hd.n_pre >= 0 && hd.n_pre <= 3, "corrupt header");
+  HX_CHECK(hd.dim >= 1 && hd.dim <= 4096, "corrupt header: dim");
+  HX_CHECK(hd.id_base >= 0 && hd.id_base + hd.n < 0xFFFFFFFFll, "corrupt header: row ids");
+  HX_CHECK(hd.nnz < 0xFFFFFFFFll && hd.sp_rows <= hd.n && (hd.sp_rows > 0 || hd.nnz == 0), "corrupt header: sparse counts");
+  {
+    const int64_t dp = round_up(hd.dim, 64), dp8 = round_up(hd.dim, 128);
+    int64_t per_row = dp * 4 + dp * 2 + dp8 + 4;
+    for (int p = 0; p < hd.n_pre; ++p) {
+      HX_CHECK(hd.psize[p] >= 64 && hd.psize[p] <= hd.dim && hd.psize[p] % 64 == 0, "corrupt header: prefix sizes");
+      per_row += (int64_t)hd.psize[p] * 4;
+    }
+    if (hd.n_pre > 0) per_row += (int64_t)hd.psize[0] * 2;
+    int64_t want = (int64_t)sizeof hd + hd.n * per_row;
+    if (hd.sp_rows > 0) want += (hd.sp_rows + 1) * 8 + hd.nnz * 8;
+    HX_CHECK(fseek(fl.f, 0, SEEK_END) == 0, "cannot seek");
+    const int64_t have = (int64_t)ftell(fl.f);
+    HX_CHECK(fseek(fl.f, (long)sizeof hd, SEEK_SET) == 0, "cannot seek");
+    HX_CHECK(have == want, "index file length does not match its header (truncated or corrupt)");
+  }
   hx_index* h = nullptr;
   const int rc = hx_create(hd.dim, hd.psize, hd.n_pre, device, hd.id_base, &h);
   if (rc != 0) return rc;
@@ -1386,6 +1721,15 @@ int hx_load(const char* path, int32_t device, hx_index** out) {
       file_to_dev(fl.f, h->sp_indptr, ((size_t)hd.sp_rows + 1) * 8, buf);
       file_to_dev(fl.f, h->sp_idx, (size_t)hd.nnz * 4, buf);
       file_to_dev(fl.f, h->sp_val, (size_t)hd.nnz * 4, buf);
+      // what the add path guarantees and the kernels rely on: monotone indptr from 0 to nnz, term ids in
+      // [0, 2^31), finite values
+      int* bad = (int*)h->ws.get(WS_MISC, 4);
+      HX_HIP(hipMemset(bad, 0, 4));
+      launch_csr_check(h->sp_indptr, h->sp_idx, hd.sp_rows, hd.nnz, bad, nullptr);
+      int hbad = 0;
+      HX_HIP(hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost));
+      HX_CHECK(hbad == 0, "corrupt index file: sparse CSR is inconsistent");
+      track_weights_dev(h, h->sp_val, hd.nnz, nullptr);
       h->sp_rows = hd.sp_rows;
       h->nnz = hd.nnz;
       h->sparse_stale = true;

@@ -142,44 +142,123 @@ void launch_prep_queries_f(const float* q_raw, int q_dim, int B, int Bpad, int d
 void launch_prep_queries_i8(const float* q_raw, int q_dim, int B, int Bpad, int dpad8, int8_t* q8,
                             float* rinv_q, hipStream_t st);
 
-// ---- sparse.hip --------------------------------------------------------------
-// Documents are cut into segments of seg_docs (one 8-byte LDS accumulator word per document of the
-// segment).  sparse.hip is compiled twice: 8192-document segments with two 512-thread workgroups
-// per CU, and 16384-document segments with one 1024-thread workgroup per CU -- fewer, larger visits,
-// 11 % faster on a 10M-document shard and 9 % slower on a 1.25M one; the engine picks per index.
-constexpr int SEG_DOCS_SMALL = 8192, SEG_DOCS_LARGE = 16384;
-// Term-major inverted index: the postings of live term i (ascending document) are
-// post[ptr[i*(n_segments+1) + 0] .. ptr[i*(n_segments+1) + n_segments]); ptr[i*(S+1) + s] is
-// the first posting of term i whose document lies in segment s or later.  A posting is
-// {document index inside its segment, fp32 weight bits}.
+// ---- sparse2.hip / sprescore.hip ------------------------------------------------
+// K7 in two passes (DESIGN.md "sparse stage"):
+//   select  -- term-at-a-time over the inverted index with a 16-bit integer accumulator per document
+//              (two documents per LDS word): segments of 32768 / 65536 documents per visit.  The integer
+//              score `a` brackets the real one (u = score * scale, a - 1.01 k <= u <= a + 0.01 k for k
+//              matching terms), so every document that can reach the exact top-L has a > a_L - M
+//              (a_L = L-th best integer score, M = the query's margin): the pass keeps exactly those;
+//   rescore -- the exact score of every kept candidate from the document-major CSR in upstream's order
+//              (query terms in ascending term id, fp32 mul, fp32 add), then the top-L by key.
+// Queries the integer pass cannot serve (a non-positive weight, more than SP_TMAX terms, a candidate
+// buffer that overflowed) are flagged and re-run document-at-a-time over all rows (k_sparse_range).
+constexpr int SEG_DOCS_SMALL = 32768, SEG_DOCS_LARGE = 65536;
+constexpr int SP_TMAX = 64;            // query terms the select pass takes (one lane each)
+// Term-major inverted index over the documents [doc0, doc0 + n_docs) of the shard: the postings of live
+// term i (ascending document) are post[ptr[i*(n_segments+1) + 0] .. ptr[i*(n_segments+1) + n_segments]);
+// ptr[i*(S+1) + s] is the first posting of term i whose document lies in segment s or later.  A posting
+// is {document index inside its segment, fp32 weight bits}.
 struct SparseIndexView {
-  const uint2* post;           // [nnz]
+  const uint2* post;           // [nnz] (+ 16 bytes of padding)
   const uint32_t* ptr;         // [n_live x (n_segments + 1)]
   const uint32_t* uterms;      // [n_live] live term ids, ascending
   int n_live;
   int64_t n_docs;
   int n_segments;
   int seg_docs;                // SEG_DOCS_SMALL or SEG_DOCS_LARGE
-  int64_t id_base;
+  int64_t id_base;             // global id of the view's first document
 };
-struct SparseQueryArgs {
-  SparseIndexView ix;
+// per-query preparation, one wave per query: validity, scale, margin, live-term index of every term
+struct SparsePrepArgs {
   const int64_t* q_indptr;     // [B+1]
   const int32_t* q_idx;        // ascending within a query
   const float* q_val;
   int B;
-  int parts;                   // blocks per query (each owns a contiguous segment range)
-  int limit;
-  uint64_t* out;               // [B x parts x limit] sorted best-first per (query, part)
-  int* out_cnt;                // [B x parts]
-  unsigned long long* stat_postings;  // optional: postings visited (profile)
-  uint64_t* cand;              // [B x parts x seg_docs] workgroup-private candidate buffers
-  unsigned long long* park;    // [B x parts x seg_docs/2] scratch for the rare two-pass harvest
-  int* q_order;                // [B] scratch: queries by descending term count (may be NULL)
+  SparseIndexView ix[2];       // base index and (optional, n_live = 0) tail index
+  float wmax;                  // largest document weight of the shard
+  int index_nonpos;            // some document weight is <= 0: the integer pass cannot bracket scores
+  int32_t* q_ti[2];            // [B x SP_TMAX] live-term index per view, -1 = absent
+  float* q_qs;                 // [B x SP_TMAX] query weight * scale
+  int* q_margin;               // [B]
+  int* q_flag;                 // [B] 0 ok, 1 = needs the document-at-a-time path, 2 = invalid (non-finite weight)
+  unsigned long long* q_work;  // [B] postings of the query's terms (both views): launch order, profile
+  unsigned long long* stat_postings;   // optional: += sum of q_work
 };
-void launch_sparse_score(const SparseQueryArgs& a, hipStream_t st);   // dispatches on a.ix.seg_docs
-namespace v8k { void launch_sparse_score_variant(const SparseQueryArgs& a, hipStream_t st); }
-namespace v16k { void launch_sparse_score_variant(const SparseQueryArgs& a, hipStream_t st); }
+void launch_sparse_prep(const SparsePrepArgs& a, hipStream_t st);
+struct SparseSelectArgs {
+  SparseIndexView ix;
+  const int64_t* q_indptr;
+  const int32_t* q_ti;         // [B x SP_TMAX] for THIS view
+  const float* q_qs;
+  const int* q_margin;
+  const int* q_flag;
+  int B;
+  int parts;                   // workgroups per query (each owns a contiguous segment range)
+  int limit;
+  int lout;                    // keys kept per (query, part) at most
+  uint64_t* out;               // [B x parts_total x lout] integer-score keys, best first, 0 = empty
+  int* out_cnt;                // [B x parts_total]
+  int parts_total, part0;      // this launch writes parts [part0, part0 + parts) of every query
+  uint64_t* cand;              // [B x parts x seg_docs/4] workgroup-private candidate buffers
+  const int* q_order;          // [B] queries, heaviest first (may be NULL)
+  int* q_fail;                 // [B] set when a buffer overflowed: the query takes the exact path
+};
+void launch_sparse_select(const SparseSelectArgs& a, hipStream_t st);   // dispatches on a.ix.seg_docs
+namespace v32k { void launch_sparse_select_variant(const SparseSelectArgs& a, hipStream_t st); }
+namespace v64k { void launch_sparse_select_variant(const SparseSelectArgs& a, hipStream_t st); }
+void launch_sparse_order(const unsigned long long* q_work, int B, int* q_order, hipStream_t st);
+// document-major CSR of the shard (what the ingest path appends)
+struct SparseCsr {
+  const int64_t* indptr;       // [n_docs + 1]
+  const int32_t* idx;
+  const float* val;
+  int64_t n_docs;
+  int64_t id_base;
+};
+// exact (upstream-order fp32) scores of the kept candidates of every query
+struct SparseRescoreArgs {
+  SparseCsr d;
+  const int64_t* q_indptr;
+  const int32_t* q_idx;
+  const float* q_val;
+  const uint64_t* cand;        // [B x stride] integer-score keys, best first
+  const int* cnt;              // [B]
+  int stride;
+  int B;
+  int limit;
+  const int* q_margin;
+  const int* q_flag;
+  uint64_t* out;               // [B x stride] exact keys of the candidates: slots [0, out_cnt[b]) (0 = foreign id)
+  int* out_cnt;                // [B] candidates = the prefix of the list within the margin of its L-th key
+  int* q_fail;                 // set when the list was cut short of the margin
+};
+void launch_sparse_rescore(const SparseRescoreArgs& a, hipStream_t st);
+// out[b] = the parts' lists of query b packed into one run (stride pt * lout), out_cnt[b] = its length
+void launch_sparse_pack(const uint64_t* parts, const int* pcnt, int B, int pt, int lout, uint64_t* out, int* out_cnt,
+                        hipStream_t st);
+// exact scores of ALL documents [row_begin, row_end) for the listed queries (document-at-a-time path).
+// tau == NULL: out[f*stride + slot0 + (row - row_begin)] = key, 0 when the document shares no term with the query.
+// tau != NULL: keys with score >= tau[f] are appended at out[f*stride + atomicAdd(cnt[f], 1)]; ovf[f] = 1 when full.
+struct SparseRangeArgs {
+  SparseCsr d;
+  const int64_t* q_indptr;
+  const int32_t* q_idx;
+  const float* q_val;
+  const int* qsel;
+  int nsel;
+  int64_t row_begin, row_end;
+  uint64_t* out;
+  int stride, slot0;
+  const float* tau;
+  int* cnt;
+  int* ovf;
+};
+void launch_sparse_range(const SparseRangeArgs& a, hipStream_t st);
+// {min, max} of val[0, n) merged into mm[0], mm[1] (fp32, device); mm[2] counts non-finite values
+void launch_minmax_f32(const float* val, int64_t n, float* mm, hipStream_t st);
+// *bad = 1 unless indptr[0] = 0, indptr is monotone up to indptr[n_rows] = nnz and every idx is >= 0
+void launch_csr_check(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int64_t nnz, int* bad, hipStream_t st);
 
 // ---- spbuild.hip -------------------------------------------------------------
 struct SparseBuildOut {
@@ -189,9 +268,10 @@ struct SparseBuildOut {
   int64_t n_live;
   int64_t ptr_entries;
 };
-// Build the segment-major inverted index from doc-major CSR on the device.
-void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,
-                        int64_t nnz, int seg_docs, SparseBuildOut* out, hipStream_t st);
+// Build the term-major inverted index of documents [doc0, doc0 + n_docs) from the doc-major CSR on the
+// device (indptr is the shard's: indptr[doc0] is the first posting taken).
+void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* val, int64_t doc0, int64_t n_docs,
+                        int seg_docs, SparseBuildOut* out, hipStream_t st);
 // Synthetic docs (oracle synth_sparse_docs): two passes.
 void synth_sparse_count(int64_t doc0_global, int64_t n, uint32_t seed, const uint32_t* cdf, int V,
                         const uint16_t* len_tab, int64_t* nnz_per_doc, hipStream_t st);

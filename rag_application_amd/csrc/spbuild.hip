@@ -1,4 +1,5 @@
-// K9 -- on-device inverted-index build, plus the synthetic sparse corpus generator.
+// K9 -- on-device inverted-index build (rocPRIM radix sort + two small kernels), plus the synthetic sparse
+// corpus generator.
 //
 // Mirrors Qdrant's sparse index build on upsert of the "sparse" named vector
 // (app/core/vector_store/qdrant/qdrant_handler.py:80-86, 163, 190-193).  Input is the
@@ -28,19 +29,21 @@ struct DevBuf {
   T* as() { return (T*)p; }
 };
 
-// one wave per document: key = term id, payload = (local document index, weight bits)
-__global__ void k_make_pairs(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,
+// one wave per document of [doc0, doc0 + n_docs): key = term id, payload = (document index relative to doc0,
+// weight bits); pair i of the output is posting indptr[doc0] + i of the CSR
+__global__ void k_make_pairs(const int64_t* indptr, const int32_t* idx, const float* val, int64_t doc0, int64_t n_docs,
                              uint32_t* keys, uint64_t* pay) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (d >= n_docs) return;
-  const int64_t b = indptr[d], e = indptr[d + 1];
+  const int64_t base = indptr[doc0];
+  const int64_t b = indptr[doc0 + d], e = indptr[doc0 + d + 1];
   for (int64_t i = b + lane; i < e; i += 64) {
-    keys[i] = (uint32_t)idx[i];
+    keys[i - base] = (uint32_t)idx[i];
     uint32_t wb;
     const float w = val[i];
     __builtin_memcpy(&wb, &w, 4);
-    pay[i] = ((uint64_t)d << 32) | wb;
+    pay[i - base] = ((uint64_t)d << 32) | wb;
   }
 }
 
@@ -70,17 +73,23 @@ __global__ __launch_bounds__(256) void k_fill_ptr(const uint64_t* pay, const uin
   }
 }
 
-void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* val, int64_t n_docs,
-                        int64_t nnz, int seg_docs, SparseBuildOut* out, hipStream_t st) {
+void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* val, int64_t doc0, int64_t n_docs,
+                        int seg_docs, SparseBuildOut* out, hipStream_t st) {
   *out = SparseBuildOut{};
-  if (nnz <= 0 || n_docs <= 0) return;
+  if (n_docs <= 0) return;
+  int64_t ends[2] = {0, 0};
+  HX_HIP(hipMemcpyAsync(&ends[0], indptr + doc0, 8, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipMemcpyAsync(&ends[1], indptr + doc0 + n_docs, 8, hipMemcpyDeviceToHost, st));
+  HX_HIP(hipStreamSynchronize(st));
+  const int64_t nnz = ends[1] - ends[0];
+  if (nnz <= 0) return;
   HX_CHECK(nnz < (int64_t)0xFFFFFFFFll, "sparse index: nnz per shard must be < 2^32");
   HX_CHECK(n_docs < (int64_t)0xFFFFFFFFll, "sparse index: documents per shard must be < 2^32");
   HX_CHECK(seg_docs == SEG_DOCS_SMALL || seg_docs == SEG_DOCS_LARGE, "bad segment size");
   const int64_t nseg = (n_docs + seg_docs - 1) / seg_docs;
 
   DevBuf k_in(nnz * 4), k_out(nnz * 4), p_in(nnz * 8), p_out(nnz * 8);
-  hipLaunchKernelGGL(k_make_pairs, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, indptr, idx, val,
+  hipLaunchKernelGGL(k_make_pairs, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, indptr, idx, val, doc0,
                      n_docs, k_in.as<uint32_t>(), p_in.as<uint64_t>());
   HX_HIP(hipGetLastError());
 
@@ -125,7 +134,8 @@ void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* 
   HX_HIP(hipGetLastError());
   HX_HIP(hipMalloc((void**)&out->uterms, (size_t)n_live * 4));
   HX_HIP(hipMemcpyAsync(out->uterms, uterms.p, (size_t)n_live * 4, hipMemcpyDeviceToDevice, st));
-  HX_HIP(hipMalloc((void**)&out->post, (size_t)nnz * sizeof(uint2)));
+  HX_HIP(hipMalloc((void**)&out->post, (size_t)(nnz + 2) * sizeof(uint2)));   // + padding: sparse2.hip loads pairs
+  HX_HIP(hipMemsetAsync(out->post + nnz, 0, 2 * sizeof(uint2), st));
   hipLaunchKernelGGL(k_make_postings, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p_out.as<uint64_t>(),
                      nnz, (uint32_t)seg_docs, out->post);
   HX_HIP(hipGetLastError());

@@ -1,0 +1,309 @@
+// K7, the passes around the select kernel (sparse2.hip): per-query preparation, launch order, the exact
+// score of the kept candidates, and the document-at-a-time path for queries the integer pass cannot serve.
+//
+// Exact score = upstream's order (oracle.OracleIndex.sparse_scores, SPARSE_FIX_BITS = None): the query's
+// terms in ascending term id, acc = acc + q_t * d_t from +0 with an fp32 multiply and an fp32 add, over
+// the terms the document holds (app/core/vector_store/qdrant/qdrant_handler.py:347-354 -> Qdrant's sparse
+// search, IDF-free).  One wave per (query, document): the lanes hold the document's terms, a ballot finds
+// the query term among them.
+#include "hx_common.hpp"
+#include "kernels.hpp"
+
+namespace hx {
+
+// live-term index of `term` by one wave in 64-ary steps: ~log64(n_live) dependent loads (`term` is
+// wave-uniform); -1 if absent
+__device__ __forceinline__ int sp_find_term_wave(const uint32_t* uterms, int n_live, uint32_t term, int lane) {
+  int lo = 0, hi = n_live;   // the first index whose term is >= `term` lies in [lo, hi]
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) >> 6;
+    const int p = lo + lane * step;
+    const bool in = p < hi;
+    const uint32_t v = in ? uterms[p] : 0xFFFFFFFFu;
+    const int c = __popcll(__ballot(in && v < term));   // ascending list: a prefix of the probes
+    if (c == 0) {
+      hi = lo + 1;
+      break;
+    }
+    const int nhi = lo + c * step + 1;                  // probe c (if any) is >= term
+    lo = lo + (c - 1) * step + 1;                       // probe c - 1 is < term
+    hi = nhi < hi ? nhi : hi;
+  }
+  const int p = lo + lane;
+  const bool in = p < hi;
+  const uint32_t v = in ? uterms[p] : 0xFFFFFFFFu;
+  const unsigned long long eq = __ballot(in && v == term);
+  return eq ? lo + (int)__builtin_ctzll(eq) : -1;
+}
+
+// ---------------------------------------------------------------------------------
+// preparation: one wave per query
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sparse_prep(SparsePrepArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= a.B) return;
+  const int64_t qb = a.q_indptr[q];
+  const int T = (int)(a.q_indptr[q + 1] - qb);
+  int flag = 0;
+  // weights: finite (else the query is invalid), positive (else the integer pass cannot bracket the score)
+  bool bad = false, nonpos = false;
+  double sum = 0.0;
+  for (int j = lane; j < T; j += 64) {
+    const float v = a.q_val[qb + j];
+    bad |= !(__builtin_fabsf(v) <= 3.0e38f);
+    nonpos |= !(v > 0.0f);
+    sum += (double)v;
+  }
+  if (__ballot(bad)) flag = 2;
+  else if (__ballot(nonpos) || a.index_nonpos || T > SP_TMAX) flag = 1;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);   // same value in every lane
+  // scale: the largest possible score maps below 65535 - T - 8 (sparse2.hip)
+  const double smax = sum * (double)a.wmax;
+  double scale = 0.0;
+  if (T > 0 && flag == 0) {
+    if (smax > 0.0 && smax < 1.0e300) scale = (double)(65535 - T - 8) / smax;
+    if (!(scale > 0.0 && scale < 1.0e30)) flag = 1;
+  }
+  // live-term index of every term in both views; postings of the query
+  unsigned long long work = 0;
+  const int Tn = T < SP_TMAX ? T : SP_TMAX;
+  for (int t = 0; t < Tn; ++t) {
+    const uint32_t term = (uint32_t)a.q_idx[qb + t];
+    for (int v = 0; v < 2; ++v) {
+      int r = -1;
+      if (a.ix[v].n_live > 0) r = sp_find_term_wave(a.ix[v].uterms, a.ix[v].n_live, term, lane);
+      if (lane == 0) {
+        a.q_ti[v][(int64_t)q * SP_TMAX + t] = r;
+        if (r >= 0) {
+          const uint32_t* row = a.ix[v].ptr + (int64_t)r * (a.ix[v].n_segments + 1);
+          work += (unsigned long long)(row[a.ix[v].n_segments] - row[0]);
+        }
+      }
+    }
+  }
+  if (lane < Tn) {
+    const float qs = (float)((double)a.q_val[qb + lane] * scale);
+    a.q_qs[(int64_t)q * SP_TMAX + lane] = qs;
+  }
+  if (lane == 0) {
+    a.q_margin[q] = T + T / 16 + 4;
+    a.q_flag[q] = flag;
+    a.q_work[q] = work;
+    if (a.stat_postings && work) atomicAdd(a.stat_postings, work);
+  }
+}
+void launch_sparse_prep(const SparsePrepArgs& a, hipStream_t st) {
+  if (a.B <= 0) return;
+  hipLaunchKernelGGL(k_sparse_prep, dim3((a.B + 3) / 4), dim3(256), 0, st, a);
+  HX_HIP(hipGetLastError());
+}
+
+// queries by descending work (longest-processing-time first): rank by counting, one block
+__global__ __launch_bounds__(1024) void k_sparse_order(const unsigned long long* work, int B, int* q_order) {
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const unsigned long long w = work[i];
+    int r = 0;
+    for (int j = 0; j < B; ++j) {
+      const unsigned long long x = work[j];
+      r += (x > w || (x == w && j < i)) ? 1 : 0;
+    }
+    q_order[r] = i;
+  }
+}
+void launch_sparse_order(const unsigned long long* q_work, int B, int* q_order, hipStream_t st) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, st, q_work, B, q_order);
+  HX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// exact score of (query, document) on one wave
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float sp_exact_score(const SparseCsr& d, int64_t doc, const int32_t* q_idx,
+                                                const float* q_val, int64_t qb, int T, int lane, bool& any) {
+  const int64_t b = d.indptr[doc], e = d.indptr[doc + 1];
+  // the document's first 128 terms live in registers; longer documents re-read the rest per query term
+  const int32_t i0 = b + lane < e ? d.idx[b + lane] : -1;
+  const int32_t i1 = b + 64 + lane < e ? d.idx[b + 64 + lane] : -1;
+  float acc = 0.0f;
+  any = false;
+  for (int t = 0; t < T; ++t) {
+    const int32_t term = q_idx[qb + t];
+    int64_t pos = -1;
+    unsigned long long m = __ballot(i0 == term);
+    if (m) pos = b + __builtin_ctzll(m);
+    else {
+      m = __ballot(i1 == term);
+      if (m) pos = b + 64 + __builtin_ctzll(m);
+      else
+        for (int64_t c = b + 128; c < e; c += 64) {
+          m = __ballot(c + lane < e && d.idx[c + lane] == term);
+          if (m) {
+            pos = c + __builtin_ctzll(m);
+            break;
+          }
+        }
+    }
+    if (pos >= 0) {                                  // wave-uniform
+      acc = __fadd_rn(acc, __fmul_rn(q_val[qb + t], d.val[pos]));
+      any = true;
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ uint32_t spr_thr(uint32_t aL, int M) {   // sparse2.hip sp_thr
+  const int t = (int)aL - M + 1;
+  return t < 1 ? 1u : (uint32_t)t;
+}
+
+// grid (SPR_BLOCKS, B): the waves of a query's blocks stride over its candidates (a list holds the top-L plus the
+// documents within the margin of the L-th: about L + 10 keys, thousands when many documents tie at the L-th score)
+constexpr int SPR_BLOCKS = 32;
+__global__ __launch_bounds__(256) void k_sparse_rescore(SparseRescoreArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  uint64_t* out = a.out + (int64_t)b * a.stride;
+  int n = 0;
+  uint32_t thr = 1u;
+  const uint64_t* list = a.cand + (int64_t)b * a.stride;
+  if (a.q_flag[b] == 0) {
+    n = a.cnt[b];
+    n = n < a.stride ? n : a.stride;
+    if (n >= a.limit) thr = spr_thr((uint32_t)(list[a.limit - 1] >> 32), a.q_margin[b]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the list is sorted by integer score: the candidates are a prefix
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((uint32_t)(list[mid] >> 32) >= thr) lo = mid + 1; else hi = mid;
+    }
+    a.out_cnt[b] = lo;
+    if (lo == a.stride) a.q_fail[b] = 1;        // a full list that passes to its last key: cut short
+  }
+  const int64_t qb = a.q_indptr[b];
+  const int T = (int)(a.q_indptr[b + 1] - qb);
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += SPR_BLOCKS * 4) {   // wave-uniform
+    const uint64_t ck = list[i];
+    if ((uint32_t)(ck >> 32) < thr) break;      // sorted: nothing further passes
+    uint64_t k = 0ull;
+    const int64_t doc = (int64_t)(0xFFFFFFFFu - (uint32_t)ck) - a.d.id_base;
+    if (doc >= 0 && doc < a.d.n_docs) {
+      bool any;
+      const float s = sp_exact_score(a.d, doc, a.q_idx, a.q_val, qb, T, lane, any);
+      if (any) k = make_key(s, (uint32_t)(a.d.id_base + doc));
+    }
+    if (lane == 0) out[i] = k;
+  }
+}
+void launch_sparse_rescore(const SparseRescoreArgs& a, hipStream_t st) {
+  if (a.B <= 0 || a.stride <= 0) return;
+  hipLaunchKernelGGL(k_sparse_rescore, dim3(SPR_BLOCKS, a.B), dim3(256), 0, st, a);
+  HX_HIP(hipGetLastError());
+}
+
+// the parts' lists of a query (each best first, `lout` slots, zeros after its count) -> one packed run + count
+__global__ __launch_bounds__(256) void k_sparse_pack(const uint64_t* parts, const int* pcnt, int pt, int lout,
+                                                     uint64_t* out, int* out_cnt) {
+  const int b = blockIdx.x;
+  int base = 0;
+  for (int p = 0; p < pt; ++p) {
+    int n = pcnt[b * pt + p];
+    n = n < lout ? n : lout;
+    for (int i = threadIdx.x; i < n; i += 256) out[(int64_t)b * pt * lout + base + i] = parts[((int64_t)b * pt + p) * lout + i];
+    base += n;
+  }
+  if (threadIdx.x == 0) out_cnt[b] = base;
+}
+void launch_sparse_pack(const uint64_t* parts, const int* pcnt, int B, int pt, int lout, uint64_t* out, int* out_cnt,
+                        hipStream_t st) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_sparse_pack, dim3(B), dim3(256), 0, st, parts, pcnt, pt, lout, out, out_cnt);
+  HX_HIP(hipGetLastError());
+}
+
+// Document-at-a-time path.  Rows [row_begin, row_end) against the listed queries: a document that shares a term
+// with the query and scores >= tau[f] appends its key to the query's buffer (slots [cnt0, cap)); a full
+// buffer sets ovf[f].  tau NULL: every row has its own slot (slot0 + row - row_begin), 0 when no term is shared.
+__global__ __launch_bounds__(256) void k_sparse_range(SparseRangeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = a.row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.row_end) return;
+  const int f = blockIdx.y;
+  const int b = a.qsel[f];
+  const int64_t qb = a.q_indptr[b];
+  bool any;
+  const float s = sp_exact_score(a.d, row, a.q_idx, a.q_val, qb, (int)(a.q_indptr[b + 1] - qb), lane, any);
+  if (lane != 0) return;
+  uint64_t* o = a.out + (int64_t)f * a.stride;
+  if (!a.tau) {
+    o[a.slot0 + (row - a.row_begin)] = any ? make_key(s, (uint32_t)(a.d.id_base + row)) : 0ull;
+  } else if (any && s >= a.tau[f]) {
+    const int pos = atomicAdd(a.cnt + f, 1);
+    if (pos < a.stride) o[pos] = make_key(s, (uint32_t)(a.d.id_base + row));
+    else a.ovf[f] = 1;
+  }
+}
+void launch_sparse_range(const SparseRangeArgs& a, hipStream_t st) {
+  const int64_t n = a.row_end - a.row_begin;
+  if (n <= 0 || a.nsel <= 0) return;
+  hipLaunchKernelGGL(k_sparse_range, dim3((unsigned)((n + 3) / 4), a.nsel), dim3(256), 0, st, a);
+  HX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// {min, max} of the document weights (as orderable u32), count of non-finite ones
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax_f32(const float* __restrict__ val, int64_t n, uint32_t* mm) {
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u, bad = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = val[i];
+    if (!(__builtin_fabsf(v) <= 3.0e38f)) {
+      ++bad;
+      continue;
+    }
+    const uint32_t u = f32_orderable(v);
+    lo = u < lo ? u : lo;
+    hi = u > hi ? u : hi;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+    bad += __shfl_xor(bad, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(mm + 0, lo);
+    atomicMax(mm + 1, hi);
+    if (bad) atomicAdd(mm + 2, bad);
+  }
+}
+void launch_minmax_f32(const float* val, int64_t n, float* mm, hipStream_t st) {
+  if (n <= 0) return;
+  const int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(k_minmax_f32, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, val, n,
+                     (uint32_t*)mm);
+  HX_HIP(hipGetLastError());
+}
+
+// a loaded CSR (hx_load): indptr[0] = 0, monotone, indptr[n] = nnz; idx >= 0
+__global__ void k_csr_check(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int64_t nnz, int* bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool b = false;
+  if (i < n_rows) b |= indptr[i] > indptr[i + 1] || indptr[i] < 0 || indptr[i + 1] > nnz;
+  if (i == 0) b |= indptr[0] != 0 || indptr[n_rows] != nnz;
+  if (i < nnz) b |= idx[i] < 0;
+  if (b) *bad = 1;
+}
+void launch_csr_check(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int64_t nnz, int* bad, hipStream_t st) {
+  const int64_t m = n_rows > nnz ? n_rows : nnz;
+  if (m <= 0) return;
+  hipLaunchKernelGGL(k_csr_check, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, indptr, idx, n_rows, nnz, bad);
+  HX_HIP(hipGetLastError());
+}
+
+}  // namespace hx

@@ -115,9 +115,8 @@ class HxIndex:
         sp_val = np.ascontiguousarray(sp_val, dtype=np.float32)
         if sp_indptr.shape[0] != n + 1:
             raise ValueError("sparse indptr must have n+1 entries")
-        # sparse first: it validates on the host before anything is committed
-        check(_lib.lib().hx_add_sparse(self._h, _ptr(sp_indptr), _ptr(sp_idx), _ptr(sp_val), n))
-        check(_lib.lib().hx_add_dense(self._h, _ptr(dense), n))
+        # dense and sparse vectors of a batch are committed together or not at all (hx_add_rows)
+        check(_lib.lib().hx_add_rows(self._h, _ptr(dense), _ptr(sp_indptr), _ptr(sp_idx), _ptr(sp_val), n))
 
     def add_device(self, dense: torch.Tensor, sp_indptr=None, sp_idx=None, sp_val=None):
         """`add` for dense rows that already live on the GPU (an encoder's output): hx_add_dense_dev."""

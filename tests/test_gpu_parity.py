@@ -520,13 +520,13 @@ def test_golden_fixtures_through_the_abi(eng, torch_mod, synth_tables):
     ix.close()
 
 
-@pytest.mark.parametrize("seg_docs", [8192, 16384])
+@pytest.mark.parametrize("seg_docs", [32768, 65536])
 def test_sparse_cold_paths(eng, torch_mod, monkeypatch, seg_docs):
-    """Both builds of the sparse kernel (8192- and 16384-document segments; the engine picks by index
-    size, HX_DEBUG_SEG_DOCS forces one).  Sparse scoring beyond the pipelined fast path: a term held by EVERY document with
-    equal weights (runs longer than a workgroup, 8192 tied survivors per segment: the
-    two-pass harvest and the id-ascending tie rule), queries with more than 12 terms (the
-    generic loop), negative weights, a term nobody holds, an empty query."""
+    """Documents with NEGATIVE weights: the integer select pass cannot bracket their scores, so every query
+    takes the document-at-a-time path (k_sparse_range) -- all rows through the exact arithmetic.  Also: a term
+    held by EVERY document with equal weights (the id-ascending tie rule), 30-term queries, a term nobody
+    holds, an empty query.  (HX_DEBUG_SEG_DOCS forces the build of the inverted index; it is built even
+    though these queries never walk it.)"""
     monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
     n, dim = 40000, 64
     rng = np.random.default_rng(9)
@@ -562,6 +562,152 @@ def test_sparse_cold_paths(eng, torch_mod, monkeypatch, seg_docs):
         for b, (ti, tv) in enumerate(queries):
             es, ei = ora.search_sparse(np.asarray(ti, np.int64), np.asarray(tv, np.float32), limit)
             assert_list_equal(s[b], i[b], c[b], es, ei, f"sparse cold b={b} L={limit}")
+    assert ix.stats()["sparse_fallback_queries"] >= 3 * len(queries)
+    ix.close()
+
+
+def _sparse_case(eng, torch_mod, ora, ix, queries, limits, what):
+    qip = np.cumsum([0] + [len(q[0]) for q in queries]).astype(np.int64)
+    qix = np.concatenate([np.asarray(q[0], np.int32) for q in queries] + [np.zeros(0, np.int32)])
+    qv = np.concatenate([np.asarray(q[1], np.float32) for q in queries] + [np.zeros(0, np.float32)])
+    for limit in limits:
+        keys, cnt = ix.search_sparse(torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qix).cuda(),
+                                     torch_mod.from_numpy(qv).cuda(), limit)
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b, (ti, tv) in enumerate(queries):
+            es, ei = ora.search_sparse(np.asarray(ti, np.int64), np.asarray(tv, np.float32), limit)
+            assert_list_equal(s[b], i[b], c[b], es, ei, f"{what} b={b} L={limit}")
+
+
+@pytest.mark.parametrize("seg_docs", [32768, 65536])
+def test_sparse_select_paths(eng, torch_mod, monkeypatch, seg_docs):
+    """Positive weights: the integer select pass serves the queries.  A term held by EVERY document with equal
+    weights (100k tied candidates: the buffer overflows, the query is flagged and served exactly), dense
+    segments (more chunks than a wave holds in registers), 30 and 64 terms (the wave-wide scan beyond one DPP
+    row), 70 terms (more than the pass takes: exact path), an absent term, an empty query."""
+    monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
+    n, dim = 100000, 64
+    rng = np.random.default_rng(10)
+    vocab = 400
+    indptr, idx, val = [0], [], []
+    for d in range(n):
+        terms = rng.choice(vocab, size=int(rng.integers(1, 40)), replace=False) + 10
+        w = rng.uniform(0.05, 2.0, len(terms)).astype(np.float32)
+        idx.extend([7] + terms.tolist())            # term 7 is in every document, weight 1.0
+        val.extend([1.0] + w.tolist())
+        indptr.append(len(idx))
+    indptr, idx, val = np.asarray(indptr, np.int64), np.asarray(idx, np.int64), np.asarray(val, np.float32)
+    X = O.synth_dense(32, 0, n, dim)
+    ora = O.OracleIndex(dim, ())
+    ora.add(X, indptr, idx, val)
+    ora.finalize()
+    ix = eng.HxIndex(dim, ())
+    ix.add(X, indptr, idx.astype(np.int32), val)
+    queries = [([7], [2.0]),                                              # all docs tie: overflow -> exact path
+               ([7, 11, 12], [1.0, 0.5, 0.25]),                           # dense runs + a tie floor
+               (list(range(10, 40)), rng.uniform(0.1, 2.0, 30).tolist()),  # 30 terms
+               (list(range(10, 74)), rng.uniform(0.1, 2.0, 64).tolist()),  # 64 terms: every lane a term
+               (list(range(10, 80)), rng.uniform(0.1, 2.0, 70).tolist()),  # 70 terms: exact path
+               ([5000], [1.0]),                                           # absent term
+               ([], []),                                                  # empty query
+               ([11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53], [1.0] * 12),
+               ([11], [0.7]), ([12, 300], [1e-3, 1e3])]
+    _sparse_case(eng, torch_mod, ora, ix, queries, (10, 100, 300, 1000), f"sparse select seg={seg_docs}")
+    st = ix.stats()
+    assert st["n_segments"] == (n + seg_docs - 1) // seg_docs
+    assert 0 < st["sparse_fallback_queries"] < 4 * len(queries)      # some, not all, took the exact path
+    ix.close()
+
+
+@pytest.mark.parametrize("seg_docs", [32768, 65536])
+def test_sparse_cut_partial_slices(eng, torch_mod, monkeypatch, seg_docs):
+    """The candidate cut of k_sparse_select with the buffer ending at every position of the waves' 256-key
+    slices: term k is held by exactly n_k documents of ONE segment, so the only visit appends n_k candidates
+    and the final cut sorts exactly n_k keys -- n_k = 256 w + r across the register cut (up to waves x 256
+    keys) and the general LDS sort beyond it."""
+    monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
+    n, dim = 30000, 64
+    counts = [1, 63, 64, 65, 100, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1500,
+              2047, 2048, 2049, 2305, 3000, 3071, 3839, 4095, 4096, 4097, 5000, 7000, 8191, 8192, 8193]
+    rng = np.random.default_rng(11)
+    rows = [[] for _ in range(n)]
+    for k, c in enumerate(counts):
+        docs = rng.choice(n, size=c, replace=False)
+        ws = rng.permutation(c).astype(np.float32) / np.float32(c) + np.float32(0.5)   # distinct weights
+        for d, w in zip(docs.tolist(), ws.tolist()):
+            rows[d].append((1000 + k, w))
+    indptr = np.zeros(n + 1, np.int64)
+    idx, val = [], []
+    for d in range(n):
+        for t, w in rows[d]:
+            idx.append(t)
+            val.append(w)
+        indptr[d + 1] = len(idx)
+    idx, val = np.asarray(idx, np.int64), np.asarray(val, np.float32)
+    X = O.synth_dense(33, 0, n, dim)
+    ora = O.OracleIndex(dim, ())
+    ora.add(X, indptr, idx, val)
+    ora.finalize()
+    ix = eng.HxIndex(dim, ())
+    ix.add(X, indptr, idx.astype(np.int32), val)
+    queries = [([1000 + k], [1.0]) for k in range(len(counts))]
+    limits = (100, 10, 256, 300)
+    _sparse_case(eng, torch_mod, ora, ix, queries, limits, f"sparse cut seg={seg_docs}")
+    # a visit that appends more keys than the buffer holds (seg_docs / 4) flags its query: served exactly
+    assert ix.stats()["sparse_fallback_queries"] == len(limits) * sum(c > seg_docs // 4 for c in counts)
+    ix.close()
+
+
+def test_sparse_incremental_tail(eng, torch_mod, synth_tables, monkeypatch):
+    """Incremental upsert: rows added after the inverted index was built go to a TAIL index (only their postings
+    are sorted); the lists equal those of an index built from scratch, and the oracle's."""
+    from oracle import c_oracle as CO
+    monkeypatch.setenv("HX_DEBUG_TAIL_MIN", "1000000")      # never rebuild the base in this test
+    n0, n1, n2, B, L = 50000, 3000, 500, 64, 100
+    n = n0 + n1 + n2
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    X = O.synth_dense(6, 0, n, 64)
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
+    ix = eng.HxIndex(64, ())
+    lo = 0
+    for hi in (n0, n0 + n1, n):
+        ix.add(X[lo:hi], ip[lo:hi + 1] - ip[lo], si[ip[lo]:ip[hi]].astype(np.int32), sv[ip[lo]:ip[hi]])
+        lo = hi
+        keys, cnt = ix.search_sparse(*tq, L)
+        s, i, c = unpack_np(eng, keys, cnt)
+        es, ei, ec = CO.InvIndex(ip[:hi + 1], si[:ip[hi]], sv[:ip[hi]]).search(qip, qsi, qsv, L)
+        for b in range(B):
+            assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"tail rows={hi} b={b}")
+    assert ix.stats()["n_segments"] == 2 + 1                  # base: 50000 rows in two segments; tail: one
+    monkeypatch.setenv("HX_DEBUG_TAIL_MIN", "0")            # from scratch: one base index over everything
+    one = eng.HxIndex(64, ())
+    one.add(X, ip, si.astype(np.int32), sv)
+    k1, c1 = one.search_sparse(*tq, L)
+    assert one.stats()["n_segments"] == 2
+    assert torch_mod.equal(k1, keys) and torch_mod.equal(c1, cnt)
+    one.close()
+    ix.close()
+
+
+def test_sparse_input_validation(eng, torch_mod):
+    """Values are checked before anything is stored; a batch is committed whole or not at all."""
+    ix = eng.HxIndex(64, ())
+    X = O.synth_dense(7, 0, 4, 64)
+    ip = np.asarray([0, 1, 2, 2, 3], np.int64)
+    for bad in (np.nan, np.inf, -np.inf, 1e30):
+        with pytest.raises(eng.HxError, match="finite"):
+            ix.add(X, ip, np.asarray([1, 2, 3], np.int32), np.asarray([1.0, bad, 1.0], np.float32))
+        assert ix.count() == 0 and ix.stats()["nnz"] == 0
+    with pytest.raises(eng.HxError, match="unique"):
+        ix.add(X, np.asarray([0, 2, 2, 2, 2], np.int64), np.asarray([5, 5], np.int32), np.ones(2, np.float32))
+    ix.add(X, ip, np.asarray([1, 2, 3], np.int32), np.asarray([1.0, 0.5, 2.0], np.float32))
+    assert ix.count() == 4 and ix.stats()["nnz"] == 3
+    # a non-finite QUERY weight is an error, not a silently wrong list
+    q = (torch_mod.tensor([0, 1], dtype=torch_mod.int64).cuda(), torch_mod.tensor([1], dtype=torch_mod.int32).cuda(),
+         torch_mod.tensor([float("nan")], dtype=torch_mod.float32).cuda())
+    with pytest.raises(eng.HxError, match="finite"):
+        ix.search_sparse(*q, 10)
     ix.close()
 
 
@@ -725,12 +871,13 @@ def test_save_load_round_trip(eng, torch_mod, synth_tables, tmp_path):
     ld.close()
 
 
-@pytest.mark.parametrize("seg_docs", [8192, 16384])
+@pytest.mark.parametrize("seg_docs", [32768, 65536])
 def test_sparse_both_segment_sizes(eng, torch_mod, synth_tables, monkeypatch, seg_docs):
-    """The synthetic Zipf corpus through either sparse build: 60k documents, 300 queries, top-100."""
+    """The synthetic Zipf corpus through either sparse build: 150k documents (a partial last segment in both),
+    300 queries, top-100."""
     from oracle import c_oracle as CO
     monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
-    n, B = 60000, 300
+    n, B = 150000, 300
     ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
     ix = eng.HxIndex(64, ())
     ix.add(O.synth_dense(5, 0, n, 64), ip, si.astype(np.int32), sv)
