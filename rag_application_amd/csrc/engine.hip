@@ -758,7 +758,7 @@ static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* 
       a.out_cnt = pc;
       a.parts_total = pt;
       a.part0 = v == 0 ? 0 : parts[0];
-      a.cand = (uint64_t*)w.get(v == 0 ? WS_SP_CAND : WS_SP_PARK, (size_t)B * parts[v] * (ixs[v]->seg_docs / 4) * 8);
+      a.cand = (uint64_t*)w.get(v == 0 ? WS_SP_CAND : WS_SP_PARK, (size_t)B * parts[v] * (ixs[v]->seg_docs + ixs[v]->seg_docs / 8) * 8);
       a.q_order = order;
       a.q_fail = fail;
       launch_sparse_select(a, st);
@@ -886,6 +886,9 @@ static bool sparse_resolve(hx_index* h, const int64_t* q_indptr, const int32_t* 
     if (flag[(size_t)b] || fail[(size_t)b]) sel.push_back(b);
   }
   if (sel.empty()) return false;
+  if (getenv("HX_DEBUG_SP_VERBOSE")) {
+    for (int b : sel) fprintf(stderr, "[hx] sparse query %d -> exact path (flag %d, fail %d)\n", b, flag[(size_t)b], fail[(size_t)b]);
+  }
   h->sparse_fallbacks += (int64_t)sel.size();
   sparse_exact_fallback(h, q_indptr, q_idx, q_val, sel, L, out_keys, out_cnt, st);
   return true;

@@ -200,7 +200,7 @@ struct SparseSelectArgs {
   uint64_t* out;               // [B x parts_total x lout] integer-score keys, best first, 0 = empty
   int* out_cnt;                // [B x parts_total]
   int parts_total, part0;      // this launch writes parts [part0, part0 + parts) of every query
-  uint64_t* cand;              // [B x parts x seg_docs/4] workgroup-private candidate buffers
+  uint64_t* cand;              // [B x parts x (seg_docs + seg_docs/8)] workgroup-private candidate buffers
   const int* q_order;          // [B] queries, heaviest first (may be NULL)
   int* q_fail;                 // [B] set when a buffer overflowed: the query takes the exact path
 };

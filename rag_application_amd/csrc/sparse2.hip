@@ -57,7 +57,10 @@ constexpr int SEG_DOCS = HX_SEG_DOCS;
 constexpr int SEG_WORDS = SEG_DOCS / 2;      // accumulator words (two documents each)
 constexpr int SEG_WSHIFT = SEG_DOCS == 65536 ? 15 : 14;
 static_assert((1 << SEG_WSHIFT) == SEG_WORDS, "segment size");
-constexpr int SP_CAP = SEG_DOCS / 4;         // candidate keys per workgroup = what the LDS can sort
+constexpr int SP_CAP = SEG_DOCS / 4;         // candidate keys the LDS can sort (the accumulator as scratch)
+constexpr int SP_GCAP = SEG_DOCS + SP_CAP / 2;   // keys of the workgroup's buffer in global memory: a visit appends
+                                             // at most one key per document of the segment
+constexpr int SP_HSHIFT = SEG_DOCS == 65536 ? 1 : 2;   // histogram pre-filter: SEG_WORDS 32-bit bins of 2 / 4 scores
 constexpr int SP_THREADS = HX_SP_THREADS;
 constexpr int SP_WAVES = SP_THREADS / 64;
 constexpr int SP_K = 4;                      // chunks per wave and visit held in registers
@@ -73,6 +76,9 @@ struct SpShared {
   int ovf;                                   // an append found the buffer full
   int redo;                                  // the register cut kept all 256: use the general cut
   uint32_t tau;                              // append threshold (integer score)
+  int n2;                                    // pre-filter: keys loaded into the sort scratch
+  uint32_t pre;                              // pre-filter threshold
+  uint32_t scan[HX_SP_THREADS];              // pre-filter: per-thread bin sums
 };
 // One object at namespace scope: every access is provably LDS (ds_* instructions).
 __shared__ SpShared g_sp;
@@ -110,7 +116,7 @@ __device__ __forceinline__ void sp_cut(uint64_t* cand, int limit, int M, int tid
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's appends have left the core
   __syncthreads();                                   // ... and every other wave's; S.cnt settled
   int n = S.cnt;
-  n = n < SP_CAP ? n : SP_CAP;
+  n = n < SP_GCAP ? n : SP_GCAP;
   bool general = !(limit <= 256 && n <= SP_WAVES * 256);   // block-uniform
   if (!general) {
     // every wave sorts 256 keys in registers (wsort.hpp), then log2(SP_WAVES) pairwise folds through the
@@ -171,9 +177,56 @@ __device__ __forceinline__ void sp_cut(uint64_t* cand, int limit, int M, int tid
     __syncthreads();
     if (!general) return;
   }
+  // ---- general cut
+  uint32_t pre = 0;
+  if (n > SP_CAP) {
+    // More keys than the LDS can sort (the first visits of a dense query, before there is a threshold): the
+    // scores are 16-bit integers, so a histogram over the (all-zero) accumulator finds a lower bound of the
+    // L-th best score, and only the keys within the margin of THAT are sorted.
+    constexpr int PER = SEG_WORDS / SP_THREADS;      // bins per thread
+    for (int i = tid; i < n; i += SP_THREADS)
+      __hip_atomic_fetch_add(&S.acc[(uint32_t)(sp_ld_key(cand + i) >> 32) >> SP_HSHIFT], 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_barrier();
+    uint32_t mine = 0;
+#pragma unroll 8
+    for (int j = 0; j < PER; ++j) mine += S.acc[tid * PER + j];
+    S.scan[tid] = mine;
+    if (tid == 0) S.pre = 1u;
+    lds_barrier();
+    uint32_t above = 0;                              // keys in the bins of the threads above this one
+    for (int t = tid + 1; t < SP_THREADS; ++t) above += S.scan[t];
+    if (above < (uint32_t)limit && above + mine >= (uint32_t)limit) {   // the L-th best key lies in this thread's bins
+      uint32_t run = above;
+      for (int j = PER - 1; j >= 0; --j) {
+        run += S.acc[tid * PER + j];
+        if (run >= (uint32_t)limit) {
+          S.pre = sp_thr((uint32_t)(tid * PER + j) << SP_HSHIFT, M);   // lower edge of the bin: <= the true a_L
+          break;
+        }
+      }
+    }
+    lds_barrier();
+    pre = S.pre;
+    for (int i = tid; i < SEG_WORDS; i += SP_THREADS) S.acc[i] = 0u;
+    if (tid == 0) S.n2 = 0;
+    lds_barrier();
+    for (int i = tid; i < n; i += SP_THREADS) {
+      const uint64_t k = sp_ld_key(cand + i);
+      if ((uint32_t)(k >> 32) >= pre) {
+        const int pos = atomicAdd(&S.n2, 1);
+        if (pos < SP_CAP) S.sort[pos] = k;
+      }
+    }
+    lds_barrier();
+    if (S.n2 > SP_CAP && tid == 0) S.ovf = 1;        // more keys within the margin than can be sorted: exact path
+    n = S.n2 < SP_CAP ? S.n2 : SP_CAP;
+  }
   int P = SP_THREADS;                                // sort size: next power of two >= n
   while (P < n) P <<= 1;
-  for (int i = tid; i < P; i += SP_THREADS) S.sort[i] = i < n ? sp_ld_key(cand + i) : 0ull;
+  if (!pre) {
+    for (int i = tid; i < P; i += SP_THREADS) S.sort[i] = i < n ? sp_ld_key(cand + i) : 0ull;
+  }
   lds_barrier();
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -213,7 +266,7 @@ __device__ __forceinline__ void sp_cut(uint64_t* cand, int limit, int M, int tid
 
 __device__ __forceinline__ void sp_append(uint64_t* cand, uint32_t a, uint32_t gid) {
   const int pos = atomicAdd(&S.cnt, 1);
-  if (pos < SP_CAP) sp_st_key(cand + pos, sp_key(a, gid));
+  if (pos < SP_GCAP) sp_st_key(cand + pos, sp_key(a, gid));
   else S.ovf = 1;
 }
 
@@ -302,7 +355,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void k_sparse_select(SparseSelectArg
   const int s0 = (int)((int64_t)nseg * part / a.parts), s1 = (int)((int64_t)nseg * (part + 1) / a.parts);
   const int64_t qb = a.q_indptr[q];
   const int T = (int)(a.q_indptr[q + 1] - qb);
-  uint64_t* cand = a.cand + (int64_t)blockIdx.x * SP_CAP;
+  uint64_t* cand = a.cand + (int64_t)blockIdx.x * SP_GCAP;
   uint64_t* o = a.out + ((int64_t)q * a.parts_total + a.part0 + part) * a.lout;
   int* ocnt = a.out_cnt + (int64_t)q * a.parts_total + a.part0 + part;
   if (a.q_flag[q] != 0 || T <= 0 || s0 >= s1) {         // block-uniform: nothing for this pass to do
@@ -379,7 +432,7 @@ __global__ __launch_bounds__(SP_THREADS, 4) void k_sparse_select(SparseSelectArg
       int cnt = __builtin_amdgcn_readfirstlane(S.cnt);
       const int trig = __builtin_amdgcn_readfirstlane(S.trig);
       const uint32_t bound = nch * SP_CH < (uint32_t)SEG_DOCS ? nch * SP_CH : (uint32_t)SEG_DOCS;
-      if (cnt > a.limit && (cnt >= trig || (uint32_t)cnt + bound > (uint32_t)SP_CAP)) {
+      if (cnt > a.limit && (cnt >= trig || (uint32_t)cnt + bound > (uint32_t)SP_GCAP)) {
         sp_cut(cand, a.limit, M, tid);
         cnt = __builtin_amdgcn_readfirstlane(S.cnt);
         if (tid == 0) {                                 // later cuts: when the buffer has grown by a few lists

@@ -624,11 +624,13 @@ def test_sparse_cut_partial_slices(eng, torch_mod, monkeypatch, seg_docs):
     """The candidate cut of k_sparse_select with the buffer ending at every position of the waves' 256-key
     slices: term k is held by exactly n_k documents of ONE segment, so the only visit appends n_k candidates
     and the final cut sorts exactly n_k keys -- n_k = 256 w + r across the register cut (up to waves x 256
-    keys) and the general LDS sort beyond it."""
+    keys), the general LDS sort beyond it, and the histogram pre-filter once n_k exceeds what the LDS sorts
+    (seg_docs / 4 keys)."""
     monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
     n, dim = 30000, 64
     counts = [1, 63, 64, 65, 100, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1500,
-              2047, 2048, 2049, 2305, 3000, 3071, 3839, 4095, 4096, 4097, 5000, 7000, 8191, 8192, 8193]
+              2047, 2048, 2049, 2305, 3000, 3071, 3839, 4095, 4096, 4097, 5000, 7000, 8191, 8192, 8193, 12000,
+              16383, 16384, 16385, 20000]
     rng = np.random.default_rng(11)
     rows = [[] for _ in range(n)]
     for k, c in enumerate(counts):
@@ -653,8 +655,7 @@ def test_sparse_cut_partial_slices(eng, torch_mod, monkeypatch, seg_docs):
     queries = [([1000 + k], [1.0]) for k in range(len(counts))]
     limits = (100, 10, 256, 300)
     _sparse_case(eng, torch_mod, ora, ix, queries, limits, f"sparse cut seg={seg_docs}")
-    # a visit that appends more keys than the buffer holds (seg_docs / 4) flags its query: served exactly
-    assert ix.stats()["sparse_fallback_queries"] == len(limits) * sum(c > seg_docs // 4 for c in counts)
+    assert ix.stats()["sparse_fallback_queries"] == 0
     ix.close()
 
 
