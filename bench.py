@@ -32,7 +32,7 @@ WORKLOADS = {
 }
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
-SPARSE_ARITH = "exact 2^40 fixed-point sums"
+SPARSE_ARITH = "16-bit integer select pass over the inverted index + exact re-score in upstream order (fp32 running sum, ascending term id)"
 PMC_PROFILE = "r01_pmc_scan_v13.json"   # committed rocprofv3 --pmc pass the `traffic` figure is read from
 
 
@@ -321,12 +321,12 @@ def main():
                     sparse_ms_per_step=prof["sparse"]["ms"] / max(args.steps, 1))
         sp = prof["sparse"]
         if sp["launches"] and sp["ms"] > 0:   # second kernel of the step, HBM-bound by construction
-            roof["second_kernel"] = dict(kernel="k_sparse_score", bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS,
+            roof["second_kernel"] = dict(kernel="k_sparse_select", bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS,
                                          achieved=sp["bytes"] / sp["ms"] / 1e6,
                                          frac=sp["bytes"] / sp["ms"] / 1e6 / PEAK_HBM_GBS,
                                          alg_gb_per_launch=sp["bytes"] / sp["launches"] / 1e9,
                                          avg_launch_ms=sp["ms"] / sp["launches"],
-                                         note="8 B per posting visited; latency-bound today (DESIGN.md)")
+                                         note="8 B per posting of the queries' terms (SURVEY 8d); HIP events around the select launches")
 
     # ---- CPU baseline + parity of the TIMED result (rank 0, N = 1 only) ------------------------------
     cpu = None

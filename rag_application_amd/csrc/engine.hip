@@ -54,7 +54,7 @@ enum WsSlot {
   WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT, WS_KEPT,
   WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC,
   WS_SP_TI0, WS_SP_TI1, WS_SP_QS, WS_SP_MARGIN, WS_SP_FLAG, WS_SP_WORK, WS_SP_FAIL, WS_SP_LIST, WS_SP_LCNT,
-  WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF
+  WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF, WS_SP_QPARTS
 };
 
 template <typename T>
@@ -720,25 +720,36 @@ static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* 
     pa.stat_postings = h->sp_counter;
   }
   launch_sparse_prep(pa, st);
-  int* order = nullptr;
-  if (B <= 4096) {
-    order = (int*)w.get(WS_SP_ORDER, (size_t)B * 4);
-    launch_sparse_order(pa.q_work, B, order, st);
-  }
-  // ---- select: parts of the base, then parts of the tail, side by side in one list buffer
+  // ---- select: parts of the base, then parts of the tail, side by side in one list buffer.  A query is cut
+  // into as many workgroups as its share of the batch's postings asks for (k_sparse_plan), up to parts[0].
   int parts[2] = {0, 0};
-  for (int v = 0; v < 2; ++v) {
-    if (ixs[v]->n_segments == 0) continue;
-    const int slots = ixs[v]->seg_docs == SEG_DOCS_LARGE ? 256 : 512;   // workgroups resident at once
-    int p = v == 0 ? (slots + B - 1) / B : 1;
-    p = std::min(p, ixs[v]->n_segments);
-    p = std::min(p, std::max(1, CAND_CAP / lout - 1));
-    parts[v] = std::max(p, 1);
+  const int pt_cap = std::max(1, CAND_CAP / lout);
+  if (h->sp_tail.n_segments) parts[1] = 1;
+  int slots = h->sp_base.seg_docs == SEG_DOCS_LARGE ? 256 : 512;   // workgroups resident at once
+  if (h->sp_base.n_segments) {
+    int p = std::min(pt_cap - parts[1], h->sp_base.n_segments);
+    if (const char* e = getenv("HX_DEBUG_SP_PTMAX")) p = std::min(p, std::max(1, atoi(e)));   // diagnostics
+    parts[0] = std::max(p, 1);
+  }
+  if (const char* e = getenv("HX_DEBUG_SP_SLOTS")) slots = std::max(1, atoi(e));                // diagnostics
+  int* qparts = nullptr;
+  int* items = nullptr;
+  int* n_items = nullptr;
+  // cutting queries into parts pays only while the batch alone cannot fill the chip twice over
+  if (parts[0]) parts[0] = std::max(1, std::min(parts[0], (2 * slots + B - 1) / B));
+  if (B <= 4096 && parts[0]) {      // (the plan ranks by counting: quadratic in the batch)
+    qparts = (int*)w.get(WS_SP_QPARTS, (size_t)B * 4);
+    items = (int*)w.get(WS_SP_ORDER, ((size_t)B * parts[0] + 1) * 4);
+    n_items = items + (size_t)B * parts[0];
+    launch_sparse_plan(pa.q_work, B, parts[0], slots, qparts, items, n_items, st);
+  } else if (parts[0]) {
+    parts[0] = 1;
   }
   const int pt = parts[0] + parts[1];
-  HX_CHECK((int64_t)pt * lout <= CAND_CAP, "sparse: limit too large");
+  HX_CHECK(pt >= 1 && (int64_t)pt * lout <= CAND_CAP, "sparse: limit too large");
   uint64_t* pk = (uint64_t*)w.get(WS_SP_PARTS, (size_t)B * pt * lout * 8);
   int* pc = (int*)w.get(WS_SP_PCNT, (size_t)B * pt * 4);
+  HX_HIP(hipMemsetAsync(pc, 0, (size_t)B * pt * 4, st));   // parts a query does not use stay empty
   {
     ProfScope ps(h, st, 2, 0.0, 0.0);
     for (int v = 0; v < 2; ++v) {
@@ -752,6 +763,9 @@ static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* 
       a.q_flag = flag;
       a.B = B;
       a.parts = parts[v];
+      a.q_parts = v == 0 ? qparts : nullptr;
+      a.items = v == 0 ? items : nullptr;
+      a.n_items = v == 0 ? n_items : nullptr;
       a.limit = L;
       a.lout = lout;
       a.out = pk;
@@ -759,7 +773,6 @@ static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* 
       a.parts_total = pt;
       a.part0 = v == 0 ? 0 : parts[0];
       a.cand = (uint64_t*)w.get(v == 0 ? WS_SP_CAND : WS_SP_PARK, (size_t)B * parts[v] * (ixs[v]->seg_docs + ixs[v]->seg_docs / 8) * 8);
-      a.q_order = order;
       a.q_fail = fail;
       launch_sparse_select(a, st);
     }

@@ -194,20 +194,24 @@ struct SparseSelectArgs {
   const int* q_margin;
   const int* q_flag;
   int B;
-  int parts;                   // workgroups per query (each owns a contiguous segment range)
+  int parts;                   // most workgroups per query; query q is cut into q_parts[q] of them
+  const int* q_parts;          // [B] in [1, parts] (NULL: all `parts`): each owns a contiguous segment range
+  const int* items;            // launch plan (NULL: workgroup b = query b / parts, part b % parts): query << 8 | part
+  const int* n_items;
   int limit;
   int lout;                    // keys kept per (query, part) at most
   uint64_t* out;               // [B x parts_total x lout] integer-score keys, best first, 0 = empty
   int* out_cnt;                // [B x parts_total]
   int parts_total, part0;      // this launch writes parts [part0, part0 + parts) of every query
   uint64_t* cand;              // [B x parts x (seg_docs + seg_docs/8)] workgroup-private candidate buffers
-  const int* q_order;          // [B] queries, heaviest first (may be NULL)
   int* q_fail;                 // [B] set when a buffer overflowed: the query takes the exact path
 };
 void launch_sparse_select(const SparseSelectArgs& a, hipStream_t st);   // dispatches on a.ix.seg_docs
 namespace v32k { void launch_sparse_select_variant(const SparseSelectArgs& a, hipStream_t st); }
 namespace v64k { void launch_sparse_select_variant(const SparseSelectArgs& a, hipStream_t st); }
-void launch_sparse_order(const unsigned long long* q_work, int B, int* q_order, hipStream_t st);
+// q_parts[q] in [1, pt_max]: workgroups the query is cut into; items[0, *n_items): query << 8 | part, heaviest first
+void launch_sparse_plan(const unsigned long long* q_work, int B, int pt_max, int slots, int* q_parts, int* items,
+                        int* n_items, hipStream_t st);
 // document-major CSR of the shard (what the ingest path appends)
 struct SparseCsr {
   const int64_t* indptr;       // [n_docs + 1]

@@ -63,8 +63,24 @@ constexpr int SP_GCAP = SEG_DOCS + SP_CAP / 2;   // keys of the workgroup's buff
 constexpr int SP_HSHIFT = SEG_DOCS == 65536 ? 1 : 2;   // histogram pre-filter: SEG_WORDS 32-bit bins of 2 / 4 scores
 constexpr int SP_THREADS = HX_SP_THREADS;
 constexpr int SP_WAVES = SP_THREADS / 64;
-constexpr int SP_K = 4;                      // chunks per wave and visit held in registers
+#ifndef HX_SP_K
+#define HX_SP_K 3
+#endif
+constexpr int SP_K = HX_SP_K;                // chunks per wave and visit held in registers
 constexpr int SP_CH = 128;                   // postings per chunk: two per lane
+
+// Diagnostic build only (-DHX_SP_STAMP): lane 0 of waves 0 and 5 accumulate s_memtime deltas per phase of a
+// visit into a debug buffer of its own (never read by the kernel, never in a timed build).
+#ifdef HX_SP_STAMP
+__device__ unsigned long long g_sp_stamps[2 * 8 * 4096];
+#define SP_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SP_STAMP(i) { const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; }
+#define SP_STAMP_FLUSH if ((tid == 0 || tid == 320) && blockIdx.x < 4096) for (int i_ = 0; i_ < 8; ++i_) g_sp_stamps[(blockIdx.x * 2 + (tid != 0)) * 8 + i_] = st_acc[i_];
+#else
+#define SP_STAMP_DECL
+#define SP_STAMP(i)
+#define SP_STAMP_FLUSH
+#endif
 
 struct SpShared {
   union {
@@ -72,7 +88,6 @@ struct SpShared {
     uint64_t sort[SP_CAP];                   // sort scratch while acc is all zero
   };
   int cnt;                                   // candidates in the workgroup's global buffer
-  int trig;                                  // cnt at which the buffer is sorted and cut
   int ovf;                                   // an append found the buffer full
   int redo;                                  // the register cut kept all 256: use the general cut
   uint32_t tau;                              // append threshold (integer score)
@@ -264,10 +279,27 @@ __device__ __forceinline__ void sp_cut(uint64_t* cand, int limit, int M, int tid
   __syncthreads();
 }
 
-__device__ __forceinline__ void sp_append(uint64_t* cand, uint32_t a, uint32_t gid) {
-  const int pos = atomicAdd(&S.cnt, 1);
-  if (pos < SP_GCAP) sp_st_key(cand + pos, sp_key(a, gid));
-  else S.ovf = 1;
+// Append the passing scores of a wave's lanes (two per lane) to the workgroup's buffer: ONE LDS atomic per
+// wave reserves the range, a lane's slot follows from the ballots (before there is a threshold every touched
+// document passes: one atomic per key on one LDS word would serialise the whole workgroup).
+__device__ __forceinline__ void sp_append2(uint64_t* cand, bool p0, uint32_t a0, uint32_t g0, bool p1, uint32_t a1,
+                                           uint32_t g1) {
+  const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0), m1 = __builtin_amdgcn_ballot_w64(p1);
+  if (!(m0 | m1)) return;                                // wave-uniform; the usual case once there is a threshold
+  const int n0 = __popcll(m0), n1 = __popcll(m1);
+  int base = 0;
+  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) base = atomicAdd(&S.cnt, n0 + n1);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const int i0 = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+  const int i1 = base + n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+  if (p0) {
+    if (i0 < SP_GCAP) sp_st_key(cand + i0, sp_key(a0, g0));
+    else S.ovf = 1;
+  }
+  if (p1) {
+    if (i1 < SP_GCAP) sp_st_key(cand + i1, sp_key(a1, g1));
+    else S.ovf = 1;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -295,17 +327,18 @@ __device__ __forceinline__ SpDir sp_dir(uint32_t p0, uint32_t p1, bool active, u
   nch = (uint32_t)__builtin_amdgcn_readlane((int)d.incl, 63);
   return d;
 }
-// chunk c of the segment: first posting, postings in it (1..128), scaled query weight.  c < nch.
-__device__ __forceinline__ void sp_chunk(const SpDir& d, float qs_lane, uint32_t c, uint32_t& off, uint32_t& cnt,
-                                         float& qs) {
+// chunk c of the segment: first posting, postings in it (1..128), term slot (lane) of its run.  c < nch.
+__device__ __forceinline__ void sp_chunk(const SpDir& d, uint32_t c, uint32_t& off, uint32_t& cnt, int& t) {
   const unsigned long long m = __builtin_amdgcn_ballot_w64(d.incl > c);
-  const int t = __builtin_ctzll(m);                     // m != 0 because c < nch = incl[63]
+  t = __builtin_ctzll(m);                               // m != 0 because c < nch = incl[63]
   const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)d.len, t);
   const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)d.incl, t) - ((len + (SP_CH - 1)) / SP_CH);
   const uint32_t j = (c - start) * SP_CH;
   off = (uint32_t)__builtin_amdgcn_readlane((int)d.p0, t) + j;
   cnt = len - j < (uint32_t)SP_CH ? len - j : (uint32_t)SP_CH;
-  qs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qs_lane), t));
+}
+__device__ __forceinline__ float sp_lane_f(float v, int t) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
 }
 
 // the two postings of lane `lane` in a chunk: {doc0, w0, doc1, w1}; only the first min(cnt - 2 lane, 2) count.
@@ -323,9 +356,19 @@ __device__ __forceinline__ void sp_add1(uint32_t doc, uint32_t v) {
   __hip_atomic_fetch_add(&S.acc[doc & (SEG_WORDS - 1)], v << ((doc >> SEG_WSHIFT) << 4), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void sp_accumulate(const uint4& p, uint32_t cnt, float qs, int lane) {
-  if ((uint32_t)(2 * lane) < cnt) sp_add1(p.x, sp_units(p.y, qs));
-  if ((uint32_t)(2 * lane + 1) < cnt) sp_add1(p.z, sp_units(p.w, qs));
+// m: bit 0 / bit 1 = the lane's first / second posting counts
+__device__ __forceinline__ uint32_t sp_lanebits(uint32_t cnt, int lane) {
+  return ((uint32_t)(2 * lane) < cnt ? 1u : 0u) | ((uint32_t)(2 * lane + 1) < cnt ? 2u : 0u);
+}
+// full: the chunk holds 128 postings (wave-uniform) -- every lane's two postings count, no predication
+__device__ __forceinline__ void sp_accumulate(const uint4& p, uint32_t m, float qs, bool full) {
+  if (full) {
+    sp_add1(p.x, sp_units(p.y, qs));
+    sp_add1(p.z, sp_units(p.w, qs));
+  } else {
+    if (m & 1u) sp_add1(p.x, sp_units(p.y, qs));
+    if (m & 2u) sp_add1(p.z, sp_units(p.w, qs));
+  }
 }
 __device__ __forceinline__ uint32_t sp_take1(uint32_t doc) {
   const uint32_t sh = (doc >> SEG_WSHIFT) << 4;
@@ -333,29 +376,41 @@ __device__ __forceinline__ uint32_t sp_take1(uint32_t doc) {
                                               __HIP_MEMORY_SCOPE_WORKGROUP);
   return (old >> sh) & 0xFFFFu;
 }
-__device__ __forceinline__ void sp_harvest(const uint4& p, uint32_t cnt, int lane, uint64_t* cand, uint32_t tau,
-                                           uint32_t gbase) {
+__device__ __forceinline__ void sp_harvest(const uint4& p, uint32_t m, uint64_t* cand, uint32_t tau, uint32_t gbase,
+                                           bool full) {
   uint32_t a0 = 0, a1 = 0;
-  if ((uint32_t)(2 * lane) < cnt) a0 = sp_take1(p.x);
-  if ((uint32_t)(2 * lane + 1) < cnt) a1 = sp_take1(p.z);
-  if (a0 >= tau && a0 != 0) sp_append(cand, a0, gbase + p.x);
-  if (a1 >= tau && a1 != 0) sp_append(cand, a1, gbase + p.z);
+  if (full) {
+    a0 = sp_take1(p.x);
+    a1 = sp_take1(p.z);
+  } else {
+    if (m & 1u) a0 = sp_take1(p.x);
+    if (m & 2u) a1 = sp_take1(p.z);
+  }
+  sp_append2(cand, a0 >= tau, a0, gbase + p.x, a1 >= tau, a1, gbase + p.z);   // tau >= 1: a cleared half never passes
 }
 
 // ---------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(SP_THREADS, 4) void k_sparse_select(SparseSelectArgs a) {
+__global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : SP_THREADS / 128) void k_sparse_select(SparseSelectArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slot = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
-  const int q = a.q_order ? a.q_order[slot] : slot;     // heaviest queries first
+  int q = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
+  if (a.items) {                                        // the launch plan: heaviest items first
+    if ((int)blockIdx.x >= *a.n_items) return;
+    const int it = a.items[blockIdx.x];
+    q = it >> 8;
+    part = it & 255;
+  }
   const int nseg = a.ix.n_segments;
-  const int s0 = (int)((int64_t)nseg * part / a.parts), s1 = (int)((int64_t)nseg * (part + 1) / a.parts);
+  int qp = a.q_parts ? a.q_parts[q] : a.parts;          // parts this query is cut into
+  qp = qp < nseg ? qp : nseg;
+  qp = qp < 1 ? 1 : qp;
+  const int s0 = part < qp ? (int)((int64_t)nseg * part / qp) : 0, s1 = part < qp ? (int)((int64_t)nseg * (part + 1) / qp) : 0;
   const int64_t qb = a.q_indptr[q];
   const int T = (int)(a.q_indptr[q + 1] - qb);
-  uint64_t* cand = a.cand + (int64_t)blockIdx.x * SP_GCAP;
+  uint64_t* cand = a.cand + (int64_t)blockIdx.x * SP_GCAP;   // (a workgroup's own scratch: any layout will do)
   uint64_t* o = a.out + ((int64_t)q * a.parts_total + a.part0 + part) * a.lout;
   int* ocnt = a.out_cnt + (int64_t)q * a.parts_total + a.part0 + part;
   if (a.q_flag[q] != 0 || T <= 0 || s0 >= s1) {         // block-uniform: nothing for this pass to do
@@ -367,7 +422,6 @@ __global__ __launch_bounds__(SP_THREADS, 4) void k_sparse_select(SparseSelectArg
   for (int i = tid; i < SEG_WORDS; i += SP_THREADS) S.acc[i] = 0u;
   if (tid == 0) {
     S.cnt = 0;
-    S.trig = 2 * a.limit < 256 ? 256 : 2 * a.limit;     // first cut early: it gives the first threshold
     S.ovf = 0;
     S.redo = 0;
     S.tau = 1u;
@@ -385,99 +439,178 @@ __global__ __launch_bounds__(SP_THREADS, 4) void k_sparse_select(SparseSelectArg
   auto clampi = [&](int x) { return x <= nseg ? x : nseg; };   // row[nseg] is the end of the term's postings
   __syncthreads();
 
-  // offsets of the segment being visited, the next one and the one after (per lane); the postings of a
-  // visit are in flight since the visit before
-  uint32_t o0 = row[clampi(s0)], o1 = row[clampi(s0 + 1)], o2 = row[clampi(s0 + 2)];
-  uint32_t nch;
-  SpDir d = sp_dir(o0, o1, active, nch);
-  uint4 cur[SP_K];
-  uint32_t ccnt[SP_K];
-  float cqs[SP_K];
-#pragma unroll
-  for (int k = 0; k < SP_K; ++k) {
-    const uint32_t c = (uint32_t)(k * SP_WAVES + wave);
-    ccnt[k] = 0;
-    cqs[k] = 0.f;
-    cur[k] = make_uint4(0, 0, 0, 0);
-    if (c < nch) {
-      uint32_t off;
-      sp_chunk(d, qs_lane, c, off, ccnt[k], cqs[k]);
-      cur[k] = sp_load2(post, off, ccnt[k], lane);
-    }
-  }
-  for (int seg = s0; seg < s1; ++seg) {
-    const uint32_t gbase = (uint32_t)(a.ix.id_base + (int64_t)seg * SEG_DOCS);
-    // ---- the next visit: directory from the offsets that have landed, its posting loads, the offsets after
-    uint32_t nch_n;
-    const SpDir dn = sp_dir(o1, o2, active, nch_n);
-    uint4 nxt[SP_K];
-    uint32_t ncnt[SP_K];
-    float nqs[SP_K];
-    const bool more = seg + 1 < s1;                     // scalar
+  // Three stages in rotation, stage(x) = x mod 3 holds everything of visit x: the run offsets of the lane's
+  // term (loaded three visits ahead), the directory and the posting registers (loaded two visits ahead).
+  // At visit s: derive the directory of s + 2 from the offsets that landed and issue its postings into
+  // stage(s + 2) (processed last visit), issue the offsets of s + 3 into stage(s) (its own were consumed two
+  // visits ago), then move stage(s) -- landed by now -- to the working registers and process it.  A stage is
+  // a fixed set of registers (the three-way branch below picks it): nothing in flight is ever copied.
+  struct Stage {
+    uint32_t olo, ohi;       // offsets of the stage's NEXT visit (pending)
+    uint32_t nch;            // scalar
+    uint4 p[SP_K];
+    uint32_t mask;           // 2 bits per slot: which of the lane's two postings count
+    uint32_t tpack;          // scalar: 6 bits per slot, the term slot of the chunk; bit 24 + k: slot k is a full chunk
+  };
+  auto load_offsets = [&](Stage& st, int x) {          // offsets of visit x: row[x], row[x + 1]
+    st.olo = row[clampi(x)];
+    st.ohi = row[clampi(x + 1)];
+  };
+  auto issue = [&](Stage& st, bool on) {               // directory from the landed offsets, then the posting loads
+    const SpDir sd = sp_dir(st.olo, st.ohi, active && on, st.nch);
+    st.mask = 0;
+    st.tpack = 0;
 #pragma unroll
     for (int k = 0; k < SP_K; ++k) {
       const uint32_t c = (uint32_t)(k * SP_WAVES + wave);
-      ncnt[k] = 0;
-      nqs[k] = 0.f;
-      nxt[k] = make_uint4(0, 0, 0, 0);
-      if (more && c < nch_n) {
-        uint32_t off;
-        sp_chunk(dn, qs_lane, c, off, ncnt[k], nqs[k]);
-        nxt[k] = sp_load2(post, off, ncnt[k], lane);
+      uint32_t off = 0, cnt = 0;
+      if (c < st.nch) {
+        int t;
+        sp_chunk(sd, c, off, cnt, t);
+        st.tpack |= ((uint32_t)t << (6 * k)) | (cnt == (uint32_t)SP_CH ? 1u << (24 + k) : 0u);
+        st.mask |= sp_lanebits(cnt, lane) << (2 * k);
       }
+      // EVERY slot loads (an empty one reads posting 0 and counts nothing): hipcc must see the same number of
+      // loads on every path, or its counted waits fall back to draining everything in flight
+      st.p[k] = sp_load2(post, off, cnt, lane);
     }
-    const uint32_t o3 = row[clampi(seg + 3)];
-    // ---- this visit
+  };
+  // one visit on stage `cur`; `nx` = stage(seg + 2).  Returns the chunks of the NEXT visit's segment.
+  SP_STAMP_DECL
+  auto visit = [&](Stage& cur, Stage& nx, const Stage& nx1, int seg, uint32_t& appended_max) {
+    SP_STAMP(0)                                         // loop control, cut check
+    // The offsets of seg + 3 (into cur.olo / cur.ohi: its own were consumed two visits ago) BEFORE the postings of
+    // seg + 2: the wait for nx's offsets -- loaded a visit ago, ahead of that visit's postings -- then leaves
+    // those postings and these two loads in flight.
+    load_offsets(cur, seg + 3);
+    issue(nx, seg + 2 < s1);
+    SP_STAMP(1)
+    const uint32_t nch = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.nch);
+    appended_max = nch * SP_CH < (uint32_t)SEG_DOCS ? nch * SP_CH : (uint32_t)SEG_DOCS;
     if (nch) {                                          // scalar: the segment holds postings of the query
-      int cnt = __builtin_amdgcn_readfirstlane(S.cnt);
-      const int trig = __builtin_amdgcn_readfirstlane(S.trig);
-      const uint32_t bound = nch * SP_CH < (uint32_t)SEG_DOCS ? nch * SP_CH : (uint32_t)SEG_DOCS;
-      if (cnt > a.limit && (cnt >= trig || (uint32_t)cnt + bound > (uint32_t)SP_GCAP)) {
-        sp_cut(cand, a.limit, M, tid);
-        cnt = __builtin_amdgcn_readfirstlane(S.cnt);
-        if (tid == 0) {                                 // later cuts: when the buffer has grown by a few lists
-          const int t = cnt + (4 * a.limit < 1024 ? 1024 : 4 * a.limit);
-          S.trig = t < SP_CAP * 3 / 4 ? t : SP_CAP * 3 / 4;
-        }
-      }
+      const uint32_t tpack = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.tpack);
+      const uint32_t mask = cur.mask;
+      const uint32_t gbase = (uint32_t)(a.ix.id_base + (int64_t)seg * SEG_DOCS);
       const uint32_t tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.tau);
 #pragma unroll
       for (int k = 0; k < SP_K; ++k)
-        if (ccnt[k]) sp_accumulate(cur[k], ccnt[k], cqs[k], lane);
-      for (uint32_t c = (uint32_t)(SP_K * SP_WAVES + wave); c < nch; c += SP_WAVES) {   // dense segment: the rest
-        uint32_t off, n;
-        float qs;
-        sp_chunk(d, qs_lane, c, off, n, qs);
-        sp_accumulate(sp_load2(post, off, n, lane), n, qs, lane);
+        sp_accumulate(cur.p[k], (mask >> (2 * k)) & 3u, sp_lane_f(qs_lane, (int)((tpack >> (6 * k)) & 63u)),
+                      (tpack >> (24 + k)) & 1u);
+      // a dense segment: the chunks beyond the prefetched ones, SP_K at a time (their loads issued together); the
+      // directory is derived again from the table (a stage does not keep it: registers)
+      SpDir d{};
+      if (nch > (uint32_t)(SP_K * SP_WAVES)) {          // scalar
+        asm volatile("" ::: "memory");                  // (keeps hipcc from hoisting these loads -- and a wait for
+        uint32_t n2;                                    // everything in flight -- onto the common path)
+        d = sp_dir(row[clampi(seg)], row[clampi(seg + 1)], active, n2);
       }
+      for (uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave); c0 < nch; c0 += SP_K * SP_WAVES) {
+        uint4 r[SP_K];
+        uint32_t rm[SP_K];
+        float rq[SP_K];
+#pragma unroll
+        for (int k = 0; k < SP_K; ++k) {
+          const uint32_t c = c0 + (uint32_t)(k * SP_WAVES);
+          rm[k] = 0;
+          rq[k] = 0.f;
+          r[k] = make_uint4(0, 0, 0, 0);
+          if (c < nch) {
+            uint32_t off, n;
+            int t;
+            sp_chunk(d, c, off, n, t);
+            rq[k] = sp_lane_f(qs_lane, t);
+            rm[k] = sp_lanebits(n, lane);
+            r[k] = sp_load2(post, off, n, lane);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < SP_K; ++k) sp_accumulate(r[k], rm[k], rq[k], false);
+      }
+      SP_STAMP(2)
       lds_barrier();                                    // ---- X: every posting of the segment is in
+      SP_STAMP(3)
 #pragma unroll
-      for (int k = 0; k < SP_K; ++k)
-        if (ccnt[k]) sp_harvest(cur[k], ccnt[k], lane, cand, tau, gbase);
-      for (uint32_t c = (uint32_t)(SP_K * SP_WAVES + wave); c < nch; c += SP_WAVES) {
-        uint32_t off, n;
-        float qs;
-        sp_chunk(d, qs_lane, c, off, n, qs);
-        sp_harvest(sp_load2(post, off, n, lane), n, lane, cand, tau, gbase);
+      for (int k = 0; k < SP_K; ++k) sp_harvest(cur.p[k], (mask >> (2 * k)) & 3u, cand, tau, gbase, (tpack >> (24 + k)) & 1u);
+      for (uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave); c0 < nch; c0 += SP_K * SP_WAVES) {
+        uint4 r[SP_K];
+        uint32_t rm[SP_K];
+#pragma unroll
+        for (int k = 0; k < SP_K; ++k) {
+          const uint32_t c = c0 + (uint32_t)(k * SP_WAVES);
+          rm[k] = 0;
+          r[k] = make_uint4(0, 0, 0, 0);
+          if (c < nch) {
+            uint32_t off, n;
+            int t;
+            sp_chunk(d, c, off, n, t);
+            rm[k] = sp_lanebits(n, lane);
+            r[k] = sp_load2(post, off, n, lane);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < SP_K; ++k) sp_harvest(r[k], rm[k], cand, tau, gbase, false);
       }
+      SP_STAMP(4)
       lds_barrier();                                    // ---- Y: acc is all zero again
+      SP_STAMP(5)
     }
-    // ---- rotate
-    o0 = o1;
-    o1 = o2;
-    o2 = o3;
-    d = dn;
-    nch = nch_n;
-#pragma unroll
-    for (int k = 0; k < SP_K; ++k) {
-      cur[k] = nxt[k];
-      ccnt[k] = ncnt[k];
-      cqs[k] = nqs[k];
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)nx1.nch);
+  };
+  // `ub` >= S.cnt (every posting of a visit could become a candidate), `trig_r`: the count at which the buffer is
+  // cut; the count is read from LDS only when the bound says a cut may be due
+  uint32_t ub = 0;
+  int trig_r = 2 * a.limit < 256 ? 256 : 2 * a.limit;   // first cut early: it gives the first threshold
+  // after a visit: does the buffer have to be cut before the next one?
+  auto cut_due = [&](uint32_t appended_max, uint32_t nch_next) {
+    const uint32_t bound = nch_next * SP_CH < (uint32_t)SEG_DOCS ? nch_next * SP_CH : (uint32_t)SEG_DOCS;
+    ub += appended_max;
+    if (ub >= (uint32_t)trig_r || ub + bound > (uint32_t)SP_GCAP) {               // scalar
+      const int cnt = __builtin_amdgcn_readfirstlane(S.cnt);       // settled: every wave is past barrier Y
+      ub = (uint32_t)cnt;
+      return cnt > a.limit && (cnt >= trig_r || (uint32_t)cnt + bound > (uint32_t)SP_GCAP);
+    }
+    return false;
+  };
+  int seg = s0;
+  for (;;) {
+    // (re)start the pipeline at `seg`: stage 0 = seg, stage 1 = seg + 1, offsets of seg + 2 in stage 2
+    Stage st0, st1, st2;
+    load_offsets(st0, seg);
+    load_offsets(st1, seg + 1);
+    issue(st0, seg < s1);
+    load_offsets(st2, seg + 2);
+    issue(st1, seg + 1 < s1);
+    // Visits until the candidate buffer has to be cut, or the range ends.  The body is three visits in a fixed
+    // rotation of the stages -- straight-line, so that a stage is the same registers on every trip and the
+    // loads in flight are never copied (a stage picked by a branch made hipcc copy all three at the loop
+    // header, behind a vmcnt(0): no prefetch at all).
+    for (;;) {
+      uint32_t am, nn;
+      if (seg >= s1) break;
+      nn = visit(st0, st2, st1, seg, am);
+      ++seg;
+      if (cut_due(am, nn)) break;
+      if (seg >= s1) break;
+      nn = visit(st1, st0, st2, seg, am);
+      ++seg;
+      if (cut_due(am, nn)) break;
+      if (seg >= s1) break;
+      nn = visit(st2, st1, st0, seg, am);
+      ++seg;
+      if (cut_due(am, nn)) break;
+    }
+    // cut (acc is all zero between visits; it drains the loads in flight); the last one gives the part's list
+    sp_cut(cand, a.limit, M, tid);
+    if (seg >= s1) break;
+    {                                                   // later cuts: when the buffer has grown by a few lists
+      const int c = __builtin_amdgcn_readfirstlane(S.cnt);
+      const int t = c + (4 * a.limit < 1024 ? 1024 : 4 * a.limit);
+      trig_r = t < SP_CAP * 3 / 4 ? t : SP_CAP * 3 / 4;
+      ub = (uint32_t)c;
     }
   }
-  (void)o0;
-  // ---- the part's list: cut once more, then the kept keys (best first)
-  sp_cut(cand, a.limit, M, tid);
+  SP_STAMP_FLUSH
+  // ---- the part's list: the kept keys (best first)
   const int nk = S.cnt;
   const int n = nk < a.lout ? nk : a.lout;
   for (int i = tid; i < a.lout; i += SP_THREADS) o[i] = i < n ? sp_ld_key(cand + i) : 0ull;
@@ -487,6 +620,12 @@ __global__ __launch_bounds__(SP_THREADS, 4) void k_sparse_select(SparseSelectArg
   }
 }
 #undef S
+
+#if defined(HX_SP_STAMP) && HX_SEG_DOCS == 65536
+extern "C" int hx_debug_sp_stamps(unsigned long long* out_host, int n) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_sp_stamps), (size_t)n * 8);
+}
+#endif
 
 void launch_sparse_select_variant(const SparseSelectArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.parts <= 0) return;

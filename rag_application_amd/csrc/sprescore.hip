@@ -100,21 +100,48 @@ void launch_sparse_prep(const SparsePrepArgs& a, hipStream_t st) {
   HX_HIP(hipGetLastError());
 }
 
-// queries by descending work (longest-processing-time first): rank by counting, one block
-__global__ __launch_bounds__(1024) void k_sparse_order(const unsigned long long* work, int B, int* q_order) {
-  for (int i = threadIdx.x; i < B; i += blockDim.x) {
-    const unsigned long long w = work[i];
-    int r = 0;
+// Launch plan, one block.  A query is cut into q_parts workgroups ("parts", each a contiguous range of segments)
+// by its share of the batch's postings -- a query far above the average would otherwise finish long after the
+// rest -- and the (query, part) items are listed by descending work per item (longest-processing-time first;
+// rank by counting).  items[k] = query << 8 | part for k < *n_items.  Consecutive workgroups land on different
+// XCDs, so the list must be dense: empty workgroups in between would leave whole XCDs without work.
+__global__ __launch_bounds__(1024) void k_sparse_plan(const unsigned long long* work, int B, int pt_max, int slots,
+                                                      int* q_parts, int* items, int* n_items) {
+  __shared__ unsigned long long part[1024];
+  unsigned long long mine = 0;
+  for (int i = threadIdx.x; i < B; i += 1024) mine += work[i];
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 512; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  const unsigned long long total = part[0];
+  // two workgroups' worth of work per resident slot keeps the tail short
+  const unsigned long long target = total / (unsigned long long)(2 * slots) + 1;
+  for (int i = threadIdx.x; i < B; i += 1024) {
+    unsigned long long p = (work[i] + target - 1) / target;
+    p = p < 1 ? 1 : (p > (unsigned long long)pt_max ? (unsigned long long)pt_max : p);
+    q_parts[i] = (int)p;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += 1024) {
+    const unsigned long long w = work[i], p = (unsigned long long)q_parts[i];
+    int pos = 0;
     for (int j = 0; j < B; ++j) {
-      const unsigned long long x = work[j];
-      r += (x > w || (x == w && j < i)) ? 1 : 0;
+      const unsigned long long x = work[j], xp = (unsigned long long)q_parts[j];
+      const bool before = x * p > w * xp || (x * p == w * xp && j < i);   // x / xp > w / p
+      pos += before ? (int)xp : 0;
     }
-    q_order[r] = i;
+    for (int k = 0; k < (int)p; ++k) items[pos + k] = (i << 8) | k;
+    atomicAdd(n_items, (int)p);
   }
 }
-void launch_sparse_order(const unsigned long long* q_work, int B, int* q_order, hipStream_t st) {
+void launch_sparse_plan(const unsigned long long* q_work, int B, int pt_max, int slots, int* q_parts, int* items,
+                        int* n_items, hipStream_t st) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, st, q_work, B, q_order);
+  HX_HIP(hipMemsetAsync(n_items, 0, 4, st));
+  hipLaunchKernelGGL(k_sparse_plan, dim3(1), dim3(1024), 0, st, q_work, B, pt_max, slots, q_parts, items, n_items);
   HX_HIP(hipGetLastError());
 }
 
