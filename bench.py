@@ -243,19 +243,33 @@ def main():
     hp = eng.make_params(P, mode=eng.HX_MODE_H1)
 
     from rag_application_amd.distributed import ShardedIndex, H1Pipeline
+    from rag_application_amd.sharded import bcast_queries
     sh = ShardedIndex(ix)      # one process per GPU; exchange = one RCCL all-gather per stage
+    if world > 1 and rank != 0:
+        # N > 1: the batch exists on the front rank only; every step starts with its broadcast (C2, one packed
+        # buffer) -- the other ranks drop their copies so that nothing but the broadcast can feed them
+        Q = None
+        if mode == "h1":
+            qip_d = qix_d = qv_d = None
     # N > 1: the exchange + fusion of a batch run on a side stream beside the local stage of the next
     pipe = H1Pipeline(sh, 100, 100, 10) if (world > 1 and (backend == "nccl" or os.environ.get("HX_BENCH_PIPE"))) \
         else None
 
+    empty_sp = (torch.zeros(B + 1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
+                torch.zeros(0, dtype=torch.float32, device=dev))
+
     def step():
-        if mode == "h1":
-            if world == 1:
+        if world == 1:
+            if mode == "h1":
                 return ix.hybrid_query(Q, qip_d, qix_d, qv_d, hp)    # whole pipeline behind one ABI call
+            return sh.search_dense(Q, 10)
+        q, ip, ixx, vv = bcast_queries(Q, *((qip_d, qix_d, qv_d) if mode == "h1" else (empty_sp if rank == 0 else (None,) * 3)),
+                                       src=0, device=dev)
+        if mode == "h1":
             if pipe is not None:
-                return pipe.submit(Q, qip_d, qix_d, qv_d)
-            return sh.hybrid_h1(Q, qip_d, qix_d, qv_d, 100, 100, 10)
-        return sh.search_dense(Q, 10)
+                return pipe.submit(q, ip, ixx, vv)
+            return sh.hybrid_h1(q, ip, ixx, vv, 100, 100, 10)
+        return sh.search_dense(q, 10)
 
     for _ in range(args.warmup):
         step()
@@ -281,7 +295,7 @@ def main():
             one = eng.HxIndex(dim, (64, 128, 256), device=local, id_base=0)
             one.reserve(rows)
             one.synth_fill(rows, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs)
-            k1, c1 = one.hybrid_query(Q, qip_d, qix_d, qv_d, hp)
+            k1, c1 = one.hybrid_query(Q, qip_d, qix_d, qv_d, hp)      # (rank 0 holds the batch)
             verified = bool(torch.equal(k1, res[0]) and torch.equal(c1, res[1]))
             one.close()
         dist.barrier()

@@ -1389,8 +1389,10 @@ int hx_rescore(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, const
   HX_CATCH
 }
 
+// Workspace of the index-free entries (hx_rrf, hx_merge, hx_h1_fuse): one per (device, calling thread), so two
+// threads fusing lists on one device never share scratch (buffers of one thread are reused in stream order).
 static hx::Workspace& static_ws(int device) {
-  static std::map<int, hx::Workspace> w;
+  static thread_local std::map<int, hx::Workspace> w;
   return w[device];
 }
 

@@ -5,6 +5,8 @@
 #include "kernels.hpp"
 #include "wsort.hpp"
 
+#include <mutex>
+
 namespace hx {
 
 // ---------------------------------------------------------------------------------
@@ -196,13 +198,19 @@ void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int ke
     HX_HIP(hipGetLastError());
     return;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    HX_HIP(hipFuncSetAttribute((const void*)k_compact<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               CAND_CAP * 8));
-    HX_HIP(hipFuncSetAttribute((const void*)k_compact<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               CAND_CAP * 8));
-    attr_set = true;
+  {   // the dynamic-LDS opt-in is a property of the function ON A DEVICE: once per device, under a lock
+    static std::mutex mu;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    HX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      HX_HIP(hipFuncSetAttribute((const void*)k_compact<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 CAND_CAP * 8));
+      HX_HIP(hipFuncSetAttribute((const void*)k_compact<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 CAND_CAP * 8));
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
   }
   if (tau_rank <= 0 || tau_rank > keep) tau_rank = keep;
   HX_CHECK(!kept_io || underflow, "compact: kept_io without an underflow flag array");

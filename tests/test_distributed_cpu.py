@@ -181,3 +181,130 @@ def test_two_rank_sharded_tree_equals_unsharded_oracle():
                 s, i = unkey(k[b, :m])
                 np.testing.assert_array_equal(i, ei)
                 np.testing.assert_array_equal(s.view(np.uint32), es.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------- the sharded front end (C2 + ingest)
+class GrowingShard(FakeShard):
+    """engine.HxIndex stand-in that also ingests: an oracle index over this rank's rows, global ids = id_base + row"""
+
+    def __init__(self, dim, msizes, id_base):
+        from oracle import oracle as O
+        super().__init__(O.OracleIndex(dim, msizes), id_base)
+
+    def add(self, dense, ip=None, ix=None, v=None):
+        self.ora.add(dense, ip, ix, v)
+
+
+def front_worker(rank, world, port, n, dim, B, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import asyncio
+    from oracle import oracle as O
+    from rag_application_amd.sharded import ShardedCollection, ShardedHandler, bcast_queries
+    tabs = O.synth_tables()
+    # -- C2 alone: the packed broadcast delivers the front rank's batch bit for bit
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, tabs)
+    got = bcast_queries(*((Q, qip, qsi.astype(np.int32), qsv) if rank == 0 else (None,) * 4))
+    assert np.array_equal(got[0].numpy(), Q) and np.array_equal(got[1].numpy(), qip)
+    assert np.array_equal(got[2].numpy(), qsi.astype(np.int32)) and np.array_equal(got[3].numpy(), qsv)
+    # -- the handler: rank 0 is the application, the others serve
+    h = ShardedHandler(index_factory=GrowingShard, ops=CpuOpsH1, dense_vector_size=dim)
+    if rank != 0:
+        h.serve()
+    else:
+        X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+        ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
+        chunks = [{"content": f"chunk {r}", "dense_embedding": X[r].tolist(),
+                   "sparse_embedding": {"indices": si[ip[r]:ip[r + 1]].tolist(), "values": sv[ip[r]:ip[r + 1]].tolist()},
+                   "chunk_metadata": {"document_id": "d", "user_id": "u", "file_name": f"f{r % 3}.txt", "chunk_number": r,
+                                      "doc_summary": "s", "description": ""}} for r in range(n)]
+        run = asyncio.run
+        try:
+            run(h.store_document_vectors([dict(chunks[0], dense_embedding=[0.0] * 7)], "u"))
+            raise AssertionError("dimension mismatch must raise")
+        except ValueError:
+            pass
+        cut = n * 2 // 3 + 1                      # two batches: blocks of different sizes on every rank
+        run(h.store_document_vectors(chunks[:cut], "u"))
+        run(h.store_document_vectors(chunks[cut:], "u"))
+        assert run(h.get_collection_chunk_count("u")) == n and run(h.get_all_containers()) == ["u"]
+        sp = [{"indices": qsi[qip[b]:qip[b + 1]].tolist()[::-1], "values": qsv[qip[b]:qip[b + 1]].tolist()[::-1]}
+              for b in range(B)]                  # reversed term order: the front end sorts by term id
+        tree = run(h.hybrid_search_batch("u", Q.tolist(), sp, top_k=12, search_params=P))
+        h1 = run(h.hybrid_search_batch("u", Q.tolist(), sp, top_k=10, search_params=P, mode="h1"))
+        one = run(h.hybrid_search("u", "text", Q[0].tolist(), sp[0], top_k=3, search_params=P))
+        assert run(h.hybrid_search("u", "text", Q[0].tolist(), sp[0], search_params=None)) == []
+        ret["tree"] = [[(p.payload["chunk_number"], p.score, p.payload["content"]) for p in row] for row in tree]
+        ret["h1"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in h1]
+        ret["one"] = [(p.payload["chunk_number"], p.score) for p in one]
+        # a second collection ingested as ONE batch: engine row ids are then in insertion order on every rank, so
+        # even the ties of the RRF scores break as in the unsharded oracle
+        run(h.store_document_vectors(chunks, "v"))
+        h1v = run(h.hybrid_search_batch("v", Q.tolist(), sp, top_k=10, search_params=P, mode="h1"))
+        ret["h1v"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in h1v]
+        run(h.delete_collection("v"))
+        run(h.delete_collection("u"))
+        assert run(h.get_collection_chunk_count("u")) == 0
+        h.shutdown()
+    # -- ingest of TEXT chunks with a per-rank encoder replica (BASELINE config 5's shape): every rank encodes its block
+    class Enc:
+        def encode(self, texts):
+            return np.stack([O.synth_dense(900 + rank * 0, int(t.split()[1]), 1, dim)[0] for t in texts]) if texts else \
+                np.zeros((0, dim), np.float32)
+    col = ShardedCollection(dim, (64, 128, 256), index_factory=GrowingShard, ops=CpuOpsH1)
+    texts = [f"row {r}" for r in range(101)]
+    seq = col.store(texts=texts if rank == 0 else None, encoder=Enc())
+    assert col.count() == 101 and col.counts.tolist() == [50, 51]
+    k, c = col.search(*((Q[:2], np.zeros(3, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32),
+                         dict(P, sparse_limit=5), "h1") if rank == 0 else (None,) * 6))
+    if rank == 0:
+        assert seq.tolist() == list(range(101))
+        ret["texts"] = col.resolve(k, c)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_front_end_from_rank0_equals_unsharded_oracle():
+    """ShardedHandler on two ranks (gloo): rank 0 ingests two batches (dealt in contiguous blocks, row counts
+    all-gathered) and queries (ONE packed broadcast per batch); rank 1 serves.  Payloads, ids and score bits of
+    the reference tree and of H1 equal the oracle on the unsharded corpus in insertion order."""
+    from oracle import oracle as O
+    n, dim, B, world = 900, 256, 4, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(front_worker, args=(world, port, n, dim, B, ret), nprocs=world, join=True)
+    tabs = O.synth_tables()
+    full = O.OracleIndex(dim, (64, 128, 256))
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
+    full.add(O.synth_dense(O.SEED_CORPUS, 0, n, dim), ip, si, sv)
+    full.finalize()
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, tabs)
+    for b in range(B):
+        sp = (qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]])
+        es, ei = O.hybrid_tree(full, Q[b], *sp, P)
+        assert [t[0] for t in ret["tree"][b]] == ei.tolist() and [t[2] for t in ret["tree"][b]] == [f"chunk {i}" for i in ei]
+        np.testing.assert_array_equal(np.array([t[1] for t in ret["tree"][b]], np.float32).view(np.uint32), es.view(np.uint32))
+        es, ei = O.hybrid_h1(full, Q[b], *sp, P["dense_limit"], P["sparse_limit"], P["final_limit"])
+        assert [t[0] for t in ret["h1v"][b]] == ei[:10].tolist()
+        np.testing.assert_array_equal(np.array([t[1] for t in ret["h1v"][b]], np.float32).view(np.uint32), es[:10].view(np.uint32))
+        # two batches: rank r's rows of batch 2 precede rank r + 1's rows of batch 1 in engine id order, so equal
+        # RRF scores may break differently from insertion order -- the scores, and the ids outside tie groups, agree
+        got_s = np.array([t[1] for t in ret["h1"][b]], np.float32)
+        np.testing.assert_array_equal(got_s.view(np.uint32), es[:10].view(np.uint32))
+        for k in range(10):
+            if (es[:10] == es[k]).sum() == 1 and (k == 9 or es[k] != es[min(k + 1, len(es) - 1)]):
+                assert ret["h1"][b][k][0] == int(ei[k])
+    es, ei = O.hybrid_tree(full, Q[0], qsi[qip[0]:qip[1]], qsv[qip[0]:qip[1]], P)
+    assert [t[0] for t in ret["one"]] == ei[:3].tolist()
+    # the text ingest: row r was encoded (on whichever rank got it) as synth_dense(900, r): dense-only H1
+    enc = O.OracleIndex(dim, (64, 128, 256))
+    enc.add(np.stack([O.synth_dense(900, r, 1, dim)[0] for r in range(101)]))
+    for b in range(2):
+        es, ei = O.rrf([enc.search_dense(Q[b], P["dense_limit"])[1], np.zeros(0, np.int64)], limit=P["final_limit"])
+        assert [t[0] for t in ret["texts"][b]] == ei.tolist()

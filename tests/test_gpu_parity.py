@@ -722,11 +722,15 @@ def _c_expected_dense(X, Q, limit, prefix=0):
     return CO.search_dense(Xn, Qn, limit)
 
 
-@pytest.mark.parametrize("B,limit,prefix", [(300, 10, 0), (257, 100, 0), (300, 100, 64), (200, 40, 128)])
-def test_scan8_large_batch(eng, torch_mod, B, limit, prefix):
+@pytest.mark.parametrize("B,limit,prefix,dim", [(300, 10, 0, 768), (257, 100, 0, 768), (300, 100, 64, 768),
+                                                (200, 40, 128, 768),
+                                                (256, 10, 0, 384),     # BASELINE config 2's row: 6 k-tiles
+                                                (300, 100, 0, 1024),   # 16 k-tiles
+                                                (260, 10, 0, 100)])    # a dimension that is no multiple of 64
+def test_scan8_large_batch(eng, torch_mod, B, limit, prefix, dim):
     """Batches above 128 queries take scan8.hip (several chunks, partial last row tile, padded
-    query tile, 1/2/12 k-tiles per row): per-wave append logs, predictive thresholds."""
-    n, dim = 70001, 768
+    query tile, 1/2/6/12/16 k-tiles per row): per-wave append logs, predictive thresholds."""
+    n = 70001
     X = O.synth_dense(41, 0, n, dim)
     Q = O.synth_dense(42, 0, B, dim) * np.float32(0.6)
     ix = eng.HxIndex(dim, (64, 128))
@@ -736,6 +740,26 @@ def test_scan8_large_batch(eng, torch_mod, B, limit, prefix):
     s, i, c = unpack_np(eng, keys, cnt)
     for b in range(B):
         assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"scan8 dense b={b}")
+    ix.close()
+
+
+def test_cfg2_full_shape(eng, torch_mod):
+    """BASELINE config 2 at its full shape: 1M x 384, dense-only cosine top-10, batch 256 -- through k_scan8 and
+    the exact re-score -- against the C restatement's brute force over all rows (ids and score bits)."""
+    from oracle import c_oracle as CO
+    n, dim, B = 1_000_000, 384, 256
+    ix = eng.HxIndex(dim, (64, 128, 256))
+    ix.synth_fill(n, O.SEED_CORPUS)                      # == oracle synth_dense (test_synth_fill_matches_oracle)
+    Q = eng.synth_queries_dense(dim, 0, B, O.SEED_QUERY)
+    keys, cnt = ix.search_dense(Q, 10)
+    s, i, c = unpack_np(eng, keys, cnt)
+    Xn = CO.cosine_preprocess(CO.synth_dense(O.SEED_CORPUS, 0, n, dim))
+    Qn = CO.cosine_preprocess(CO.synth_dense(O.SEED_QUERY, 0, B, dim))
+    np.testing.assert_array_equal(Q.cpu().numpy(), CO.synth_dense(O.SEED_QUERY, 0, B, dim))
+    es, ei, ec = CO.search_dense(Xn, Qn, 10)
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"cfg2 b={b}")
+    assert ix.stats()["dense_fallback_queries"] == 0
     ix.close()
 
 
