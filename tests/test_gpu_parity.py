@@ -733,7 +733,7 @@ def test_scan8_large_batch(eng, torch_mod, B, limit, prefix, dim):
     n = 70001
     X = O.synth_dense(41, 0, n, dim)
     Q = O.synth_dense(42, 0, B, dim) * np.float32(0.6)
-    ix = eng.HxIndex(dim, (64, 128))
+    ix = eng.HxIndex(dim, tuple(m for m in (64, 128) if m <= dim))
     ix.add(X)
     es, ei, ec = _c_expected_dense(X, Q, limit, prefix)
     keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit, prefix)
