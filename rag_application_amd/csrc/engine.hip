@@ -419,11 +419,26 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   a.hitcnt = hitcnt;
   a.logcap = logcap;
   int* kept = (int*)h->ws.get(WS_KEPT, (size_t)B * 4);
-  int64_t r0 = 0, r1 = std::min<int64_t>(h->n, g.C);
+  // Scan order (kernels.hpp): logical 256-row tile t is physical tile (t * mul) mod tiles, mul ~ 0.618 * tiles and
+  // coprime to it, so every chunk samples the whole matrix evenly -- a topically clustered corpus stays
+  // exchangeable for the predictive thresholds.  The logical range is [0, tiles * 256): rows past n count nothing.
+  const int64_t n_tiles = (h->n + 255) / 256;
+  const int64_t n_log = n_tiles * 256;
+  a.n_total = h->n;
+  a.perm_n = 0;
+  a.perm_mul = 1;
+  if (n_tiles >= 8 && !getenv("HX_DEBUG_NO_PERM")) {
+    uint64_t m = (uint64_t)((double)n_tiles * 0.6180339887498949) | 1ull;
+    while (std::gcd<uint64_t, uint64_t>(m, (uint64_t)n_tiles) != 1) m += 2;
+    a.perm_n = (uint32_t)n_tiles;
+    a.perm_mul = (uint32_t)(m % (uint64_t)n_tiles);
+    a.perm_inv = 1.0 / (double)n_tiles;
+  }
+  int64_t r0 = 0, r1 = std::min<int64_t>(n_log, g.C);
   // threshold -inf, flags 0; the first chunk passes every row into slot (row - r0): its count is known
   launch_scan_init(tau, cnt, ovf, kept, B, (int)(r1 - r0), st);
   int chk_rank = 0;   // rank whose score is the threshold of the chunk being scanned (0: none)
-  while (r0 < h->n) {
+  while (r0 < n_log) {
     a.row_begin = r0;
     a.row_end = r1;
     a.hitlog = r0 > 0 ? hitlog : nullptr;   // the first chunk passes every row: k_scan, one slot per row
@@ -445,7 +460,7 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
       }
     }
     // rows per launch bounded so the kernel's 32-bit tile counters cannot wrap
-    const int64_t next = std::min<int64_t>(h->n, std::min<int64_t>(r1 * g.grow, r1 + (1ll << 27)));
+    const int64_t next = std::min<int64_t>(n_log, std::min<int64_t>(r1 * g.grow, r1 + (1ll << 27)));
     const int next_rank = (g.predictive && next > r1) ? predict_rank(g.Lp, (double)next / (double)r1) : g.Lp;
     launch_compact(cand, g.C, cnt, B, g.Lp, 0, cand, g.C, cnt, tau, g.C, st, next_rank, chk_rank, kept, ovf);
     chk_rank = next_rank < g.Lp ? next_rank : 0;

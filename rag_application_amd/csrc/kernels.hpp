@@ -37,9 +37,29 @@ struct ScanArgs {
   int* hitcnt;             // [SCAN8_WAVES] entries written (may exceed logcap: the rest set overflow[q])
   int logcap;
   // k_scan only: tau is -inf and rows_end - row_begin <= cap, so every row has its own slot
-  // (row - row_begin, key 0 for a NaN score) and no counter is touched: the caller presets cnt.
+  // (row - row_begin, key 0 for a NaN score or a row past n_total) and no counter is touched: the caller presets cnt.
   int all_pass;
+  // Scan order.  [row_begin, row_end) are LOGICAL rows: logical 256-row tile t is physical tile
+  // (t * perm_mul) mod perm_n (perm_n = 0: identity).  The stride is about 0.618 of the tile count, so every chunk of
+  // the geometric scan is an even sample of the whole matrix: a corpus ingested document by document is topically
+  // clustered, and a cluster that sat in ONE chunk would push hundreds of rows past a threshold that was set before
+  // the scan reached it (buffer overflow, retry, exact path).  Row ids and validity follow the PHYSICAL row:
+  // id = id_base + physical row, valid iff physical row < n_total.
+  int64_t n_total;
+  uint32_t perm_mul, perm_n;
+  double perm_inv;         // 1.0 / perm_n
 };
+// (t * mul) mod n for t, mul < n < 2^24 (row ids are below 2^32, a tile is 256 rows): the product is exact in a
+// double, the quotient estimate is off by at most one -- a handful of instructions instead of a 64-bit division
+// inside the scan's tile cursor
+__host__ __device__ inline uint32_t scan_phys_tile(uint32_t t, uint32_t mul, uint32_t n, double inv_n) {
+  if (!n) return t;
+  const double x = (double)t * (double)mul, dn = (double)n;
+  double r = x - __builtin_floor(x * inv_n) * dn;
+  r = r < 0.0 ? r + dn : r;
+  r = r >= dn ? r - dn : r;
+  return (uint32_t)r;
+}
 constexpr int SCAN8_WAVES = 256 * 8;   // waves of the largest scan8 grid
 constexpr int SCAN8_LOGCAP = 4096;      // most entries per wave log (expected: a few hundred per launch)
 #ifndef HX_S8_TS

@@ -105,16 +105,22 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
   const uint8_t* a_tile = nullptr;
   const uint8_t* q_tile = nullptr;
   int64_t a_off[A_LPW], b_off[B_LPW];
+  // first PHYSICAL row of the rt-th tile of this launch (kernels.hpp: scan order)
+  auto phys_row0 = [&](int rt) {
+    const int64_t lrow = a.row_begin + (int64_t)rt * BM;            // logical
+    const uint32_t pt = scan_phys_tile((uint32_t)(lrow >> 8), a.perm_mul, a.perm_n, a.perm_inv);
+    return (int64_t)pt * 256 + (lrow & 255);
+  };
   auto set_tile = [&]() {
     const int rt = (lj / nq) * 8 + xcd, qt = lj % nq;
-    const int64_t row0 = a.row_begin + (int64_t)rt * BM;
-    const int64_t left = a.row_end - row0;             // >= 1 for every tile a block is given
+    const int64_t row0 = phys_row0(rt);
+    const int64_t left = a.n_total - row0;             // valid rows of the tile (<= 0: a tile past the end)
     a_tile = a.A + row0 * a.row_bytes;
     q_tile = a.Q + (int64_t)qt * BN * a.row_bytes;
 #pragma unroll
     for (int c = 0; c < A_LPW; ++c) {
       const int trow = (wave + NW * c) * 8 + rin;
-      const int64_t erow = trow < left ? trow : left - 1;
+      const int64_t erow = trow < left ? trow : (left >= 1 ? left - 1 : -row0);   // clamp to a row that exists
       a_off[c] = erow * a.row_bytes + ((pslot ^ ((trow >> 1) & 7)) << 4);
     }
 #pragma unroll
@@ -218,7 +224,8 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
         if constexpr (KIND == KIND_I8) rq = qok ? g_rinv_q[q] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const int64_t row0 = a.row_begin + (int64_t)rt * BM + wm * (TM * 32) + i * 32 + 4 * h;
+          const int64_t lrow0 = a.row_begin + (int64_t)rt * BM + wm * (TM * 32) + i * 32 + 4 * h;   // logical
+          const int64_t row0 = phys_row0(rt) + wm * (TM * 32) + i * 32 + 4 * h;                    // physical
           float sc[16];
           if constexpr (KIND == KIND_F16) {
 #pragma unroll
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               // rows row0+8g .. +3 ; rinv_x is padded past n_rows so this never faults
-              const f32x4 rx = *(const GF4*)(g_rinv_x + row0 + 8 * g);
+              const f32x4 rx = *(const GF4*)(g_rinv_x + (row0 + 8 * g < a.n_total ? row0 + 8 * g : 0));
               sc[4 * g + 0] = ((float)acc[i][j][4 * g + 0] * rx.x) * rq;
               sc[4 * g + 1] = ((float)acc[i][j][4 * g + 1] * rx.y) * rq;
               sc[4 * g + 2] = ((float)acc[i][j][4 * g + 2] * rx.z) * rq;
@@ -241,11 +248,12 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-              if (a.all_pass) {   // first chunk: slot = row, nothing to count
-                if (qok && row < a.row_end)
-                  g_cand[(int64_t)q * a.cap + (row - a.row_begin)] =
-                      sc[e] >= tau ? make_key(sc[e], (uint32_t)(a.id_base + row)) : 0ull;
-              } else if (sc[e] >= tau && row < a.row_end) {
+              if (a.all_pass) {   // first chunk: slot = logical row, nothing to count
+                const int64_t slot = lrow0 + (e & 3) + 8 * (e >> 2) - a.row_begin;
+                if (qok && slot < a.row_end - a.row_begin)
+                  g_cand[(int64_t)q * a.cap + slot] =
+                      (row < a.n_total && sc[e] >= tau) ? make_key(sc[e], (uint32_t)(a.id_base + row)) : 0ull;
+              } else if (sc[e] >= tau && row < a.n_total) {
                 const int pos = __hip_atomic_fetch_add(g_cnt + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (pos < a.cap)
                   g_cand[(int64_t)q * a.cap + pos] = make_key(sc[e], (uint32_t)(a.id_base + row));

@@ -146,10 +146,15 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     int koff;
   };
   int lj = i0;          // item of cursor c2
+  // physical 256-row tile of the rt-th tile of this launch (kernels.hpp: scan order); scalar
+  auto phys_tile = [&](int rt) __attribute__((always_inline)) {
+    return (int)__builtin_amdgcn_readfirstlane(
+        (int)scan_phys_tile((uint32_t)((a.row_begin >> 8) + rt), a.perm_mul, a.perm_n, a.perm_inv));
+  };
   auto tile_ptrs = [&](int j, Cur& c) __attribute__((always_inline)) {
     const int d = __builtin_amdgcn_readfirstlane(j / nq);   // keep the cursor in scalar registers
     const int rt = DBG == 1 ? 0 : d * 8 + xcd, qt = j - d * nq;
-    c.a = a.A + (a.row_begin + (int64_t)rt * 256) * a.row_bytes;
+    c.a = a.A + (int64_t)phys_tile(rt) * 256 * a.row_bytes;
     c.q = a.Q + (int64_t)qt * 256 * a.row_bytes;
   };
   auto advance = [&](Cur& c) __attribute__((always_inline)) {
@@ -228,8 +233,9 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   auto filter = [&](int rt, int qt, int ha, int hb, acc_t (&c)[MT][NT]) __attribute__((always_inline)) {
     // lane owns query column r of each of the NT tiles and, per row tile, EPT rows:
     //   TS = 32: rows 8*(e>>2) + 4*hh + (e&3);  TS = 16: rows 4*hh + e   (4 consecutive per group)
+    // (rt is the PHYSICAL tile here: ktile maps it once per item)
     const int q0 = qt * 256 + wn * 64 + hb * 32 + r;
-    const int64_t rowq = a.row_begin + (int64_t)rt * 256 + wm * 128 + ha * 64 + 4 * hh;
+    const int64_t rowq = (int64_t)rt * 256 + wm * 128 + ha * 64 + 4 * hh;
     // (plain fmaxf / max chains: hipcc forms v_max3 itself, and -- unlike an inline-asm v_max3 --
     // gets the MFMA-result wait states its hazard recognizer inserts for instructions it knows)
     auto max3 = [](float x, float y, float z) __attribute__((always_inline)) {
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     if constexpr (KIND == KIND_I8) {
       // constant address space + uniform index = s_load_dword
       typedef __attribute__((address_space(4))) const float CF;
-      rxm = ((CF*)a.rinv_tile_max)[(a.row_begin >> 8) + rt];
+      rxm = ((CF*)a.rinv_tile_max)[rt];
     }
     bool any = false;
 #pragma unroll
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     int rt = 0, qt = 0;
     if (last) {
       const int d = __builtin_amdgcn_readfirstlane(cj / nq);
-      rt = d * 8 + xcd;
+      rt = phys_tile(d * 8 + xcd);
       qt = cj - d * nq;
     }
 
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     int rt = 0, qt = 0;
     if (last) {
       const int d = __builtin_amdgcn_readfirstlane(cj / nq);
-      rt = d * 8 + xcd;
+      rt = phys_tile(d * 8 + xcd);
       qt = cj - d * nq;
     }
     // phase X
@@ -615,11 +621,11 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st) {
   const unsigned sg = (unsigned)((g + S8_SB - 1) / S8_SB) * 4;
   if (kind == KIND_F16)
     hipLaunchKernelGGL((k_scatter_log<KIND_F16, HX_S8_TS>), dim3(sg), dim3(1024), 0, st, a.hitlog, a.hitcnt, a.logcap,
-                       (int)g, a.nq_tiles, a.tau, a.row_end, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt, a.overflow,
+                       (int)g, a.nq_tiles, a.tau, a.n_total, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt, a.overflow,
                        a.cap);
   else
     hipLaunchKernelGGL((k_scatter_log<KIND_I8, HX_S8_TS>), dim3(sg), dim3(1024), 0, st, a.hitlog, a.hitcnt, a.logcap,
-                       (int)g, a.nq_tiles, a.tau, a.row_end, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt, a.overflow,
+                       (int)g, a.nq_tiles, a.tau, a.n_total, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt, a.overflow,
                        a.cap);
   HX_HIP(hipGetLastError());
 }

@@ -780,11 +780,15 @@ def test_scan8_i8_large_batch(eng, torch_mod):
     ix.close()
 
 
-def test_scan8_underflow_retry(eng, torch_mod):
+@pytest.mark.parametrize("order", ["physical", "strided"])
+def test_scan8_underflow_retry(eng, torch_mod, monkeypatch, order):
     """The predictive threshold (rank kq < L' of the rows seen so far) assumes later rows look like
-    earlier ones.  Here the best rows all sit in the first chunk: later chunks append nothing,
-    kq + appended < L', k_compact flags the queries and they are re-run with the classic rule --
-    results stay exact."""
+    earlier ones.  Here the best rows all sit in the first rows of the matrix.  Scanned in physical order
+    (HX_DEBUG_NO_PERM) later chunks append nothing, kq + appended < L', k_compact flags the queries and they are
+    re-run with the classic rule; in the engine's strided tile order the same rows are spread over the chunks
+    and nothing is flagged.  Results are exact either way."""
+    if order == "physical":
+        monkeypatch.setenv("HX_DEBUG_NO_PERM", "1")
     n, dim, B, limit = 60000, 256, 200, 10
     rng = np.random.default_rng(5)
     Q = O.synth_dense(52, 0, B, dim)
@@ -798,7 +802,32 @@ def test_scan8_underflow_retry(eng, torch_mod):
     s, i, c = unpack_np(eng, keys, cnt)
     for b in range(B):
         assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"underflow b={b}")
-    assert ix.stats()["retry_queries"] > 0, "the underflow path was not exercised"
+    if order == "physical":
+        assert ix.stats()["retry_queries"] > 0, "the underflow path was not exercised"
+    assert ix.stats()["dense_fallback_queries"] == 0
+    ix.close()
+
+
+def test_clustered_row_order_stays_on_the_fast_path(eng, torch_mod):
+    """A corpus ingested document by document is topically clustered: the rows most similar to a query sit
+    together.  With the scan's strided tile order (kernels.hpp) every chunk samples the whole matrix, so clusters of
+    5000 rows -- first, in the middle or last in ingest order -- neither overflow the candidate buffers into the exact
+    path nor change a result."""
+    n, dim, B, limit, CL = 300000, 256, 300, 100, 5000
+    X = O.synth_dense(61, 0, n, dim)
+    Q = O.synth_dense(62, 0, B, dim)
+    rng = np.random.default_rng(7)
+    for t, at in enumerate((0, n // 2, n - CL)):            # three topic queries, three places
+        w = rng.uniform(0.05, 0.6, CL).astype(np.float32)[:, None]   # ascending-ish similarity inside the run
+        X[at:at + CL] = (np.sort(w, axis=0) * Q[t] + 0.5 * X[at:at + CL]).astype(np.float32)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    es, ei, ec = _c_expected_dense(X, Q, limit)
+    keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit)
+    s, i, c = unpack_np(eng, keys, cnt)
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"clustered b={b}")
+    assert ix.stats()["dense_fallback_queries"] == 0
     ix.close()
 
 
