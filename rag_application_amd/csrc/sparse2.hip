@@ -49,6 +49,9 @@
 #ifndef HX_SP_THREADS
 #define HX_SP_THREADS 512
 #endif
+#ifndef HX_SP_EXP
+#define HX_SP_EXP 0      // timing experiments only (wrong results): 1-3 LDS atomics removed, 4 no posting loads, 5 aligned loads
+#endif
 
 namespace hx {
 namespace HX_SP_VARIANT {
@@ -94,7 +97,9 @@ struct SpShared {
   int n2;                                    // pre-filter: keys loaded into the sort scratch
   uint32_t pre;                              // pre-filter threshold
   uint32_t scan[HX_SP_THREADS];              // pre-filter: per-thread bin sums
+  uint32_t otab[HX_SEG_DOCS == 65536 ? 6144 : 2560];   // run offsets of the query's terms for a window of segments
 };
+constexpr int SP_OT = HX_SEG_DOCS == 65536 ? 6144 : 2560;
 // One object at namespace scope: every access is provably LDS (ds_* instructions).
 __shared__ SpShared g_sp;
 #define S g_sp
@@ -346,6 +351,11 @@ __device__ __forceinline__ float sp_lane_f(float v, int t) {
 struct __attribute__((aligned(8))) SpPair { uint32_t x, y, z, w; };
 __device__ __forceinline__ uint4 sp_load2(const uint2* post, uint32_t off, uint32_t cnt, int lane) {
   const uint32_t i = (uint32_t)(2 * lane) < cnt ? (uint32_t)(2 * lane) : 0u;   // (the array is padded by one posting)
+#if HX_SP_EXP == 4      // timing experiment: no posting loads at all
+  return make_uint4((off + i) & 0xFFFFu, 0x3f800000u, (off + i + 1) & 0xFFFFu, 0x3f800000u);
+#elif HX_SP_EXP == 5    // timing experiment: 16-byte aligned loads (reads the wrong pair for odd offsets)
+  return *(const uint4*)(post + ((off + i) & ~1u));
+#endif
   const SpPair p = *(const SpPair*)(post + off + i);
   return make_uint4(p.x, p.y, p.z, p.w);
 }
@@ -353,8 +363,12 @@ __device__ __forceinline__ uint32_t sp_units(uint32_t wbits, float qs) {
   return (uint32_t)__fmul_rn(__builtin_bit_cast(float, wbits), qs) + 1u;       // trunc(w * qs) + 1
 }
 __device__ __forceinline__ void sp_add1(uint32_t doc, uint32_t v) {
+#if HX_SP_EXP == 2 || HX_SP_EXP == 3
+  S.acc[doc & (SEG_WORDS - 1)] = v << ((doc >> SEG_WSHIFT) << 4);
+#else
   __hip_atomic_fetch_add(&S.acc[doc & (SEG_WORDS - 1)], v << ((doc >> SEG_WSHIFT) << 4), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 // m: bit 0 / bit 1 = the lane's first / second posting counts
 __device__ __forceinline__ uint32_t sp_lanebits(uint32_t cnt, int lane) {
@@ -372,6 +386,11 @@ __device__ __forceinline__ void sp_accumulate(const uint4& p, uint32_t m, float 
 }
 __device__ __forceinline__ uint32_t sp_take1(uint32_t doc) {
   const uint32_t sh = (doc >> SEG_WSHIFT) << 4;
+#if HX_SP_EXP == 1 || HX_SP_EXP == 3
+  const uint32_t o = S.acc[doc & (SEG_WORDS - 1)];
+  ((uint16_t*)&S.acc[doc & (SEG_WORDS - 1)])[doc >> SEG_WSHIFT] = 0;
+  return (o >> sh) & 0xFFFFu;
+#endif
   const uint32_t old = __hip_atomic_fetch_and(&S.acc[doc & (SEG_WORDS - 1)], ~(0xFFFFu << sh), __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_WORKGROUP);
   return (old >> sh) & 0xFFFFu;
@@ -434,9 +453,30 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
     qs_lane = a.q_qs[(int64_t)q * SP_TMAX + lane];
   }
   const bool active = ti >= 0;
-  const uint32_t* row = a.ix.ptr + (int64_t)(active ? ti : 0) * (nseg + 1);
   const uint2* post = a.ix.post;
-  auto clampi = [&](int x) { return x <= nseg ? x : nseg; };   // row[nseg] is the end of the term's postings
+  // The run offsets (table rows of the query's terms) live in LDS for a window of W1 consecutive segments: one
+  // coalesced fill by the whole workgroup every W1 - 3 visits instead of two 64-line gathers per wave and visit
+  // -- and no table load queued in front of the posting loads any more.  Entry (t, x) = first posting of term
+  // t in segment x or later (x clamped to the end of the term's postings).
+  const int Tn = T < SP_TMAX ? T : SP_TMAX;
+  const int W1 = SP_OT / (Tn > 0 ? Tn : 1);
+  int w0 = s0;                                                  // first segment of the window
+  auto fill_window = [&](int from) {                            // workgroup-wide; ends with a barrier
+    w0 = from;
+    for (int i = tid; i < Tn * W1; i += SP_THREADS) {
+      const int t = i / W1, x = from + (i - t * W1);
+      const int r = a.q_ti[(int64_t)q * SP_TMAX + t];
+      S.otab[i] = r >= 0 ? a.ix.ptr[(int64_t)r * (nseg + 1) + (x <= nseg ? x : nseg)] : 0u;
+    }
+    __syncthreads();
+  };
+  auto offs = [&](int x, uint32_t& lo, uint32_t& hi) {          // offsets of segment x: needs w0 <= x, x + 1 < w0 + W1
+    lo = hi = 0;
+    if (lane < Tn) {
+      lo = S.otab[lane * W1 + (x - w0)];
+      hi = S.otab[lane * W1 + (x - w0) + 1];
+    }
+  };
   __syncthreads();
 
   // Three stages in rotation, stage(x) = x mod 3 holds everything of visit x: the run offsets of the lane's
@@ -446,18 +486,15 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
   // visits ago), then move stage(s) -- landed by now -- to the working registers and process it.  A stage is
   // a fixed set of registers (the three-way branch below picks it): nothing in flight is ever copied.
   struct Stage {
-    uint32_t olo, ohi;       // offsets of the stage's NEXT visit (pending)
     uint32_t nch;            // scalar
     uint4 p[SP_K];
     uint32_t mask;           // 2 bits per slot: which of the lane's two postings count
     uint32_t tpack;          // scalar: 6 bits per slot, the term slot of the chunk; bit 24 + k: slot k is a full chunk
   };
-  auto load_offsets = [&](Stage& st, int x) {          // offsets of visit x: row[x], row[x + 1]
-    st.olo = row[clampi(x)];
-    st.ohi = row[clampi(x + 1)];
-  };
-  auto issue = [&](Stage& st, bool on) {               // directory from the landed offsets, then the posting loads
-    const SpDir sd = sp_dir(st.olo, st.ohi, active && on, st.nch);
+  auto issue = [&](Stage& st, int x, bool on) {        // directory of segment x from the table, then the posting loads
+    uint32_t olo, ohi;
+    offs(x, olo, ohi);
+    const SpDir sd = sp_dir(olo, ohi, active && on, st.nch);
     st.mask = 0;
     st.tpack = 0;
 #pragma unroll
@@ -479,11 +516,7 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
   SP_STAMP_DECL
   auto visit = [&](Stage& cur, Stage& nx, const Stage& nx1, int seg, uint32_t& appended_max) {
     SP_STAMP(0)                                         // loop control, cut check
-    // The offsets of seg + 3 (into cur.olo / cur.ohi: its own were consumed two visits ago) BEFORE the postings of
-    // seg + 2: the wait for nx's offsets -- loaded a visit ago, ahead of that visit's postings -- then leaves
-    // those postings and these two loads in flight.
-    load_offsets(cur, seg + 3);
-    issue(nx, seg + 2 < s1);
+    issue(nx, seg + 2, seg + 2 < s1);                   // postings of seg + 2: two visits ahead
     SP_STAMP(1)
     const uint32_t nch = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.nch);
     appended_max = nch * SP_CH < (uint32_t)SEG_DOCS ? nch * SP_CH : (uint32_t)SEG_DOCS;
@@ -499,10 +532,11 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
       // a dense segment: the chunks beyond the prefetched ones, SP_K at a time (their loads issued together); the
       // directory is derived again from the table (a stage does not keep it: registers)
       SpDir d{};
-      if (nch > (uint32_t)(SP_K * SP_WAVES)) {          // scalar
-        asm volatile("" ::: "memory");                  // (keeps hipcc from hoisting these loads -- and a wait for
-        uint32_t n2;                                    // everything in flight -- onto the common path)
-        d = sp_dir(row[clampi(seg)], row[clampi(seg + 1)], active, n2);
+      if (nch > (uint32_t)(SP_K * SP_WAVES)) {          // scalar: more chunks than the prefetched slots
+        asm volatile("" ::: "memory");                  // (keeps hipcc from hoisting this onto the common path)
+        uint32_t n2, olo, ohi;
+        offs(seg, olo, ohi);
+        d = sp_dir(olo, ohi, active, n2);
       }
       for (uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave); c0 < nch; c0 += SP_K * SP_WAVES) {
         uint4 r[SP_K];
@@ -572,32 +606,42 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
     return false;
   };
   int seg = s0;
+  fill_window(s0);
   for (;;) {
-    // (re)start the pipeline at `seg`: stage 0 = seg, stage 1 = seg + 1, offsets of seg + 2 in stage 2
+    // (re)start the pipeline at `seg`: stage 0 = seg, stage 1 = seg + 1
     Stage st0, st1, st2;
-    load_offsets(st0, seg);
-    load_offsets(st1, seg + 1);
-    issue(st0, seg < s1);
-    load_offsets(st2, seg + 2);
-    issue(st1, seg + 1 < s1);
+    st2.nch = 0;
+    st2.mask = 0;
+    st2.tpack = 0;
+#pragma unroll
+    for (int k = 0; k < SP_K; ++k) st2.p[k] = make_uint4(0, 0, 0, 0);
+    issue(st0, seg, seg < s1);
+    issue(st1, seg + 1, seg + 1 < s1);
     // Visits until the candidate buffer has to be cut, or the range ends.  The body is three visits in a fixed
     // rotation of the stages -- straight-line, so that a stage is the same registers on every trip and the
     // loads in flight are never copied (a stage picked by a branch made hipcc copy all three at the loop
     // header, behind a vmcnt(0): no prefetch at all).
+    bool cut = false;
+    const int wend = w0 + W1 - 4;                       // last segment whose visit finds seg + 3 inside the window
     for (;;) {
       uint32_t am, nn;
-      if (seg >= s1) break;
+      if (seg >= s1 || seg > wend) break;
       nn = visit(st0, st2, st1, seg, am);
       ++seg;
-      if (cut_due(am, nn)) break;
-      if (seg >= s1) break;
+      if ((cut = cut_due(am, nn))) break;
+      if (seg >= s1 || seg > wend) break;
       nn = visit(st1, st0, st2, seg, am);
       ++seg;
-      if (cut_due(am, nn)) break;
-      if (seg >= s1) break;
+      if ((cut = cut_due(am, nn))) break;
+      if (seg >= s1 || seg > wend) break;
       nn = visit(st2, st1, st0, seg, am);
       ++seg;
-      if (cut_due(am, nn)) break;
+      if ((cut = cut_due(am, nn))) break;
+    }
+    if (!cut && seg < s1) {                             // the window is used up: the next one starts at `seg`
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (loads issued for visits that restart below)
+      fill_window(seg);
+      continue;
     }
     // cut (acc is all zero between visits; it drains the loads in flight); the last one gives the part's list
     sp_cut(cand, a.limit, M, tid);
