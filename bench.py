@@ -33,7 +33,7 @@ WORKLOADS = {
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
 SPARSE_ARITH = "16-bit integer select pass over the inverted index + exact re-score in upstream order (fp32 running sum, ascending term id)"
-PMC_PROFILE = "r01_pmc_scan_v13.json"   # committed rocprofv3 --pmc pass the `traffic` figure is read from
+PMC_PROFILE = "r02_pmc_scan.json"   # committed rocprofv3 --pmc pass the `traffic` figure is read from
 
 
 def parse():

@@ -125,13 +125,23 @@ __global__ __launch_bounds__(1024) void k_sparse_plan(const unsigned long long* 
     q_parts[i] = (int)p;
   }
   __syncthreads();
+  // the batch's work and parts in LDS (B <= 4096): the ranking below reads them B times per thread
+  __shared__ unsigned int s_w[4096];     // work per part, scaled to 32 bits (the order needs no more)
+  __shared__ unsigned char s_p[4096];
+  int sh = 0;
+  while ((total >> sh) > 0xFFFFFFFFull) ++sh;      // no query's work exceeds the batch total
   for (int i = threadIdx.x; i < B; i += 1024) {
-    const unsigned long long w = work[i], p = (unsigned long long)q_parts[i];
+    s_w[i] = (unsigned int)((work[i] >> sh) / (unsigned long long)q_parts[i]);
+    s_p[i] = (unsigned char)q_parts[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += 1024) {
+    const unsigned int w = s_w[i];
+    const unsigned long long p = (unsigned long long)q_parts[i];
     int pos = 0;
     for (int j = 0; j < B; ++j) {
-      const unsigned long long x = work[j], xp = (unsigned long long)q_parts[j];
-      const bool before = x * p > w * xp || (x * p == w * xp && j < i);   // x / xp > w / p
-      pos += before ? (int)xp : 0;
+      const unsigned int x = s_w[j];
+      pos += (x > w || (x == w && j < i)) ? (int)s_p[j] : 0;
     }
     for (int k = 0; k < (int)p; ++k) items[pos + k] = (i << 8) | k;
     atomicAdd(n_items, (int)p);
