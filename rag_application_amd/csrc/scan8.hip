@@ -19,17 +19,22 @@
 // Schedule.  Stream order of half-tiles: g = 4*T + {A0, B0, B1, A1}; slot = g mod 8
 // (8 x 16 KiB ring).  A k-tile is two phases of two quadrants each (HX_S8_PH = 2; the
 // one-quadrant-per-phase form, HX_S8_PH = 4, has twice the barriers and measured 5-7 % slower):
-//     L segment : ds_read the fragments this phase needs, one counted s_waitcnt vmcnt
+//     L segment : ds_read the fragments this phase needs, the four loads of half-tiles g+6, g+7 (HX_S8_LDMA = 1,
+//                 round 2), one counted s_waitcnt vmcnt
 //     barrier
-//     M segment : the 32 MFMAs of two quadrants with the four loads of half-tiles g+6, g+7
-//                 issued between them
+//     M segment : the 32 MFMAs of two quadrants, back to back (round 1 issued the four loads between them: a
+//                 global_load_lds costs the MFMA stream 40-60 cycles of issue, the wave in its L segment has them
+//                 to spare -- +2.6 ... +3.4 % on the 10M-row scan, interleaved A/B on one box)
 //     barrier
-//   X: reads A0, B0, B1(T) | C00 += A0.B0, C01 += A0.B1 | stages B1, A1 of T+1 | vmcnt(4)
-//   Y: reads A1(T)         | C11 += A1.B1, C10 += A1.B0 | stages A0, B0 of T+2 | vmcnt(2)
-// RAW: the wait of X retires g <= 4T+3 (4T+4, 4T+5 may be in flight), the wait of Y retires
-// g <= 4T+6 (only 4T+7 in flight), each ahead of the barrier before the reading phase.
-// WAR: slot(g) is restaged by g+8 in the M segment of the phase after its last read, i.e.
-// behind one more barrier than the reads (which every wave retires with lgkmcnt(0) first).
+//   X: reads A0, B0, B1(T), stages B1, A1 of T+1 | vmcnt(8) | C00 += A0.B0, C01 += A0.B1
+//   Y: reads A1(T),         stages A0, B0 of T+2 | vmcnt(6) | C11 += A1.B1, C10 += A1.B0
+// RAW: the wait of X retires g <= 4T+3 (4T+4 .. 4T+7 may be in flight), the wait of Y retires
+// g <= 4T+6 (4T+7 .. 4T+9 in flight), each ahead of the barrier before the reading phase.
+// WAR: slot(g) is restaged by g+8 in the L segment one phase after its last read by THIS wave group; the
+// other group reads one barrier later, so the restage is still one barrier behind every read of the slot
+// (which every wave retires with lgkmcnt(0) first).  Intervals I0 = L(X)T of group 0, group 1 one behind:
+// A1(T) is read at I2 / I3 and restaged at I4 / I5; A0, B0(T) read at I0 / I1, restaged at I2 / I3; B1(T)
+// read at I0 / I1, restaged at I4 / I5.
 // Waves 4..7 (wm = 1) run one barrier behind waves 0..3, so on every SIMD one wave is in
 // its M segment while its partner is in its L segment: the matrix pipe never waits for
 // LDS reads or load issue.  Per-query thresholds live in LDS (no VGPR-destination global
@@ -431,15 +436,23 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   // 4T+5 may be in flight), the wait of Y retires g <= 4T+6 (only 4T+7 in flight), each ahead
   // of the barrier before the reading phase.  WAR: slot(g) is restaged by g+8 in the M segment
   // of the phase after its last read, i.e. behind one more barrier than the reads.
-#define S8_QUAD(ACC, BF, HA, HB, BASE, KOFF, OFF, SLOT)                         \
+#ifndef HX_S8_LDMA
+#define HX_S8_LDMA 1   // where the four global_load_lds of a phase are issued: 0 between the MFMAs of its M segment (round 1),
+#endif                 // 1 in its L segment -- by the wave that is NOT on the matrix pipe -- 2 half and half
+
+#define S8_QUAD(ACC, BF, HA, HB, BASE, KOFF, OFF, SLOT, INM)                    \
   mma(ACC, BF, FIRST, 0, KS / 2);                                               \
-  __builtin_amdgcn_sched_barrier(0);                                            \
-  stage1(BASE, KOFF, OFF, SLOT, 0);                                             \
-  __builtin_amdgcn_sched_barrier(0);                                            \
+  if (INM) {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    stage1(BASE, KOFF, OFF, SLOT, 0);                                           \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+  }                                                                             \
   mma(ACC, BF, FIRST, KS / 2, KS);                                              \
-  __builtin_amdgcn_sched_barrier(0);                                            \
-  stage1(BASE, KOFF, OFF, SLOT, 1);                                             \
-  __builtin_amdgcn_sched_barrier(0);                                            \
+  if (INM) {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    stage1(BASE, KOFF, OFF, SLOT, 1);                                           \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+  }                                                                             \
   if (__builtin_expect(last, 0)) filter(rt, qt, HA, HB, ACC);
 #define S8_L_END(N)                                                             \
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                      \
@@ -467,15 +480,27 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     read_a(S0 + 0);
     read_b(S0 + 1, bA);
     read_b(S0 + 2, bB);
-    S8_L_END(4)
-    S8_QUAD(acc[0][0], bA, 0, 0, c1.q, c1.koff, offB[1], N0 + 2)
-    S8_QUAD(acc[0][1], bB, 0, 1, c1.a, c1.koff, offA[1], N0 + 3)
+    // HX_S8_LDMA 1: both half-tiles of the phase staged here (the wait then leaves 8 pieces in flight: g = 4T+4 ..
+    // 4T+7); 2: B1 here, A1 between the MFMAs of the second quadrant (6 in flight: 4T+4 .. 4T+6)
+    if (HX_S8_LDMA) {
+      __builtin_amdgcn_sched_barrier(0);
+      stage(c1.q, c1.koff, offB[1], N0 + 2);
+      if (HX_S8_LDMA == 1) stage(c1.a, c1.koff, offA[1], N0 + 3);
+    }
+    S8_L_END(HX_S8_LDMA == 1 ? 8 : (HX_S8_LDMA == 2 ? 6 : 4))
+    S8_QUAD(acc[0][0], bA, 0, 0, c1.q, c1.koff, offB[1], N0 + 2, HX_S8_LDMA == 0)
+    S8_QUAD(acc[0][1], bB, 0, 1, c1.a, c1.koff, offA[1], N0 + 3, HX_S8_LDMA != 1)
     S8_M_END()
     // phase Y
     read_a(S0 + 3);
-    S8_L_END(2)
-    S8_QUAD(acc[1][1], bB, 1, 1, c2.a, c2.koff, offA[0], S0 + 0)
-    S8_QUAD(acc[1][0], bA, 1, 0, c2.q, c2.koff, offB[0], S0 + 1)
+    if (HX_S8_LDMA) {      // (6 pieces in flight: g = 4T+7 .. 4T+9)
+      __builtin_amdgcn_sched_barrier(0);
+      stage(c2.a, c2.koff, offA[0], S0 + 0);
+      stage(c2.q, c2.koff, offB[0], S0 + 1);
+    }
+    S8_L_END(HX_S8_LDMA ? 6 : 2)
+    S8_QUAD(acc[1][1], bB, 1, 1, c2.a, c2.koff, offA[0], S0 + 0, HX_S8_LDMA == 0)
+    S8_QUAD(acc[1][0], bA, 1, 0, c2.q, c2.koff, offB[0], S0 + 1, HX_S8_LDMA == 0)
     S8_M_END()
 
     c1 = c2;
