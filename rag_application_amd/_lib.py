@@ -93,6 +93,11 @@ def lib() -> C.CDLL:
         if not os.path.exists(path):
             raise HxError(f"{path} is missing: run `python -m rag_application_amd.build` "
                           "(the engine has no CPU fallback)")
+        try:   # PyTorch's HIP runtime first: loaded the other way round, libhx's calls see no device
+            import torch
+            torch.cuda.is_available()
+        except Exception:
+            pass
         l = C.CDLL(path)
         for name, args in _SIGS.items():
             f = getattr(l, name)
