@@ -115,7 +115,7 @@ struct hx_index {
   bool prof = false;
   std::vector<ProfRec> prof_recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
-  unsigned long long* sp_counter = nullptr;   // postings visited by k_sparse_score while profiling
+  unsigned long long* sp_counter = nullptr;   // postings of the queries' terms (k_sparse_prep) while profiling
 
   void set_device() const { HX_HIP(hipSetDevice(device)); }
 };

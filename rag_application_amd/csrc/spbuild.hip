@@ -4,7 +4,7 @@
 // Mirrors Qdrant's sparse index build on upsert of the "sparse" named vector
 // (app/core/vector_store/qdrant/qdrant_handler.py:80-86, 163, 190-193).  Input is the
 // doc-major CSR the ingest path appends; output is the TERM-major posting store of
-// sparse.hip: postings sorted by (term, document), the ascending list of live terms, and a
+// sparse2.hip: postings sorted by (term, document), the ascending list of live terms, and a
 // dense [live term x segment] table of posting offsets (so a workgroup that walks the
 // segments in order finds every run by indexing -- no hashing, no probing -- and a term's
 // runs of consecutive segments are adjacent in memory).

@@ -1,6 +1,6 @@
 // In-register bitonic sorting network of one wave: 256 64-bit keys, 4 per lane, index i = lane * 4 + e,
 // descending.  Strides below 4 are register swaps, the rest lane exchanges (no LDS traffic of its own, no
-// barrier).  Used by k_compact_top256 (select.hip) and the candidate cut of k_sparse_score (sparse.hip).
+// barrier).  Used by k_compact_top256 (select.hip) and the candidate cut of k_sparse_select (sparse2.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
