@@ -132,6 +132,49 @@ def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000):
                 checked="ids and fp32 score bits of the LAST TIMED STEP's lists for the sampled queries")
 
 
+def ingest_leg(eng, torch, local, t_build, rows, nnz):
+    """BASELINE config 5 on one GPU: the index build of this run (timed around synth_fill + finalize, so it
+    includes generating the synthetic rows) and a bounded run of the 'batched encode' leg -- a bge-base-shaped
+    BERT (random init: no checkpoint ships), bf16, the reference's unmasked mean pooling
+    (app/core/models/huggingface/huggingface.py:165-170), its output appended where it lies (hx_add_dense_dev)."""
+    out = dict(what="config 5 legs on ONE GPU (ranks ingest their own deal of the chunks: sharded.ShardedCollection.store)",
+               index_build=dict(rows=rows, postings=nnz, seconds_incl_synthetic_generation=t_build,
+                                chunks_per_sec=rows / t_build))
+    try:
+        from transformers import BertConfig, BertModel
+        Bn, S, NB = 256, 128, 12
+        torch.manual_seed(0)
+        cfg = BertConfig(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                         intermediate_size=3072, max_position_embeddings=512)
+        model = BertModel(cfg, add_pooling_layer=False).to(f"cuda:{local}").to(torch.bfloat16).eval()
+        ids = torch.randint(1000, 30000, (Bn, S), device=f"cuda:{local}")
+        mask = torch.ones((Bn, S), dtype=torch.long, device=f"cuda:{local}")
+        sc = eng.HxIndex(768, (64, 128, 256), device=local)
+        sc.reserve(Bn * (NB + 3))
+
+        def step():
+            with torch.no_grad():
+                e = model(input_ids=ids, attention_mask=mask).last_hidden_state.mean(dim=1)
+            sc.add_device(e.float())
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(NB):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["encode_and_append"] = dict(encoder="BERT-base shape (bge-base), random init, bf16", batch=Bn, seq_len=S,
+                                        batches=NB, chunks_per_sec=Bn * NB / dt, rows_in_index=sc.count())
+        sc.close()
+        del model
+        torch.cuda.empty_cache()
+    except Exception as e:       # the encoder is PyTorch plumbing around the path, not the path: report and move on
+        out["encode_and_append"] = dict(error=repr(e)[:200])
+    return out
+
+
 def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, steps=3):
     """Side measurements on the driver record: the reference tree on the same index, the
     bandwidth-bound dense kNN (B = 1 / 8 / 32) on the same corpus, and BASELINE config 2."""
@@ -350,6 +393,7 @@ def main():
             hp_tree = eng.make_params(P, mode=eng.HX_MODE_TREE)
             side = secondary(eng, synth, torch, ix, wl, tabs, Q, (qip_d, qix_d, qv_d) if mode == "h1" else None,
                              local, hp_tree)
+            side["ingest"] = ingest_leg(eng, torch, local, t_build, rows, ix.stats()["nnz"])
         if not args.no_cpu_baseline:
             gs, gi = eng.unpack(res[0])
             res_np = (gs.cpu().numpy(), gi.cpu().numpy(), res[1].cpu().numpy())

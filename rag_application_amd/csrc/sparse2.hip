@@ -50,7 +50,7 @@
 #define HX_SP_THREADS 512
 #endif
 #ifndef HX_SP_EXP
-#define HX_SP_EXP 0      // timing experiments only (wrong results): 1-3 LDS atomics removed, 4 no posting loads, 5 aligned loads
+#define HX_SP_EXP 0      // timing experiments only (wrong results): 1-3 LDS atomics removed, 4 no posting loads, 5 aligned loads, 6 no LDS traffic
 #endif
 
 namespace hx {
@@ -363,7 +363,9 @@ __device__ __forceinline__ uint32_t sp_units(uint32_t wbits, float qs) {
   return (uint32_t)__fmul_rn(__builtin_bit_cast(float, wbits), qs) + 1u;       // trunc(w * qs) + 1
 }
 __device__ __forceinline__ void sp_add1(uint32_t doc, uint32_t v) {
-#if HX_SP_EXP == 2 || HX_SP_EXP == 3
+#if HX_SP_EXP == 6      // timing experiment: no LDS traffic at all
+  asm volatile("" ::"v"(v << ((doc >> SEG_WSHIFT) << 4)), "v"(doc & (SEG_WORDS - 1)));
+#elif HX_SP_EXP == 2 || HX_SP_EXP == 3
   S.acc[doc & (SEG_WORDS - 1)] = v << ((doc >> SEG_WSHIFT) << 4);
 #else
   __hip_atomic_fetch_add(&S.acc[doc & (SEG_WORDS - 1)], v << ((doc >> SEG_WSHIFT) << 4), __ATOMIC_RELAXED,
@@ -386,6 +388,9 @@ __device__ __forceinline__ void sp_accumulate(const uint4& p, uint32_t m, float 
 }
 __device__ __forceinline__ uint32_t sp_take1(uint32_t doc) {
   const uint32_t sh = (doc >> SEG_WSHIFT) << 4;
+#if HX_SP_EXP == 6
+  return (doc >> 31) + (sh >> 8);
+#endif
 #if HX_SP_EXP == 1 || HX_SP_EXP == 3
   const uint32_t o = S.acc[doc & (SEG_WORDS - 1)];
   ((uint16_t*)&S.acc[doc & (SEG_WORDS - 1)])[doc >> SEG_WSHIFT] = 0;

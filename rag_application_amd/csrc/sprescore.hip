@@ -100,58 +100,72 @@ void launch_sparse_prep(const SparsePrepArgs& a, hipStream_t st) {
   HX_HIP(hipGetLastError());
 }
 
-// Launch plan, one block.  A query is cut into q_parts workgroups ("parts", each a contiguous range of segments)
-// by its share of the batch's postings -- a query far above the average would otherwise finish long after the
-// rest -- and the (query, part) items are listed by descending work per item (longest-processing-time first;
-// rank by counting).  items[k] = query << 8 | part for k < *n_items.  Consecutive workgroups land on different
-// XCDs, so the list must be dense: empty workgroups in between would leave whole XCDs without work.
+// Launch plan.  A query is cut into q_parts workgroups ("parts", each a contiguous range of segments) by its share
+// of the batch's postings -- a query far above the average would otherwise finish long after the rest -- and the
+// (query, part) items are listed by descending work per item (longest-processing-time first; rank by counting).
+// items[k] = query << 8 | part for k < *n_items.  Consecutive workgroups land on different XCDs, so the list must
+// be dense: empty workgroups in between would leave whole XCDs without work.
+// Every block derives the batch's totals and parts again (B <= 4096 values: cheaper than a second launch) and
+// ranks 64 of the queries, 16 lanes per query.
 __global__ __launch_bounds__(1024) void k_sparse_plan(const unsigned long long* work, int B, int pt_max, int slots,
                                                       int* q_parts, int* items, int* n_items) {
   __shared__ unsigned long long part[1024];
+  __shared__ unsigned int s_w[4096];     // work per part, scaled to 32 bits (the order needs no more)
+  __shared__ unsigned char s_p[4096];
+  const int tid = threadIdx.x;
   unsigned long long mine = 0;
-  for (int i = threadIdx.x; i < B; i += 1024) mine += work[i];
-  part[threadIdx.x] = mine;
+  for (int i = tid; i < B; i += 1024) mine += work[i];
+  part[tid] = mine;
   __syncthreads();
   for (int off = 512; off >= 1; off >>= 1) {
-    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    if (tid < off) part[tid] += part[tid + off];
     __syncthreads();
   }
   const unsigned long long total = part[0];
+  __syncthreads();
   // two workgroups' worth of work per resident slot keeps the tail short
   const unsigned long long target = total / (unsigned long long)(2 * slots) + 1;
-  for (int i = threadIdx.x; i < B; i += 1024) {
-    unsigned long long p = (work[i] + target - 1) / target;
-    p = p < 1 ? 1 : (p > (unsigned long long)pt_max ? (unsigned long long)pt_max : p);
-    q_parts[i] = (int)p;
-  }
-  __syncthreads();
-  // the batch's work and parts in LDS (B <= 4096): the ranking below reads them B times per thread
-  __shared__ unsigned int s_w[4096];     // work per part, scaled to 32 bits (the order needs no more)
-  __shared__ unsigned char s_p[4096];
   int sh = 0;
   while ((total >> sh) > 0xFFFFFFFFull) ++sh;      // no query's work exceeds the batch total
-  for (int i = threadIdx.x; i < B; i += 1024) {
-    s_w[i] = (unsigned int)((work[i] >> sh) / (unsigned long long)q_parts[i]);
-    s_p[i] = (unsigned char)q_parts[i];
+  unsigned long long np = 0;
+  for (int i = tid; i < B; i += 1024) {
+    unsigned long long p = (work[i] + target - 1) / target;
+    p = p < 1 ? 1 : (p > (unsigned long long)pt_max ? (unsigned long long)pt_max : p);
+    s_w[i] = (unsigned int)((work[i] >> sh) / p);
+    s_p[i] = (unsigned char)p;
+    np += p;
+    if (blockIdx.x == 0) q_parts[i] = (int)p;
   }
+  part[tid] = np;
   __syncthreads();
-  for (int i = threadIdx.x; i < B; i += 1024) {
+  if (blockIdx.x == 0) {
+    for (int off = 512; off >= 1; off >>= 1) {
+      if (tid < off) part[tid] += part[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) *n_items = (int)part[0];
+  }
+  const int i = blockIdx.x * 64 + (tid >> 4), sl = tid & 15;
+  int pos = 0;
+  if (i < B) {
     const unsigned int w = s_w[i];
-    const unsigned long long p = (unsigned long long)q_parts[i];
-    int pos = 0;
-    for (int j = 0; j < B; ++j) {
+    for (int j = sl; j < B; j += 16) {
       const unsigned int x = s_w[j];
       pos += (x > w || (x == w && j < i)) ? (int)s_p[j] : 0;
     }
-    for (int k = 0; k < (int)p; ++k) items[pos + k] = (i << 8) | k;
-    atomicAdd(n_items, (int)p);
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) pos += __shfl_xor(pos, off, 64);
+  if (i < B && sl == 0) {
+    const int p = (int)s_p[i];
+    for (int k = 0; k < p; ++k) items[pos + k] = (i << 8) | k;
   }
 }
 void launch_sparse_plan(const unsigned long long* q_work, int B, int pt_max, int slots, int* q_parts, int* items,
                         int* n_items, hipStream_t st) {
   if (B <= 0) return;
-  HX_HIP(hipMemsetAsync(n_items, 0, 4, st));
-  hipLaunchKernelGGL(k_sparse_plan, dim3(1), dim3(1024), 0, st, q_work, B, pt_max, slots, q_parts, items, n_items);
+  HX_CHECK(B <= 4096 && pt_max <= 255, "sparse plan: batch too large");
+  hipLaunchKernelGGL(k_sparse_plan, dim3((B + 63) / 64), dim3(1024), 0, st, q_work, B, pt_max, slots, q_parts, items, n_items);
   HX_HIP(hipGetLastError());
 }
 

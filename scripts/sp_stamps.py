@@ -12,6 +12,13 @@ tabs = synth.tables()
 ix = eng.HxIndex(64, ())
 ix.synth_fill(N, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs); ix.finalize()
 qip, qix, qv = synth.sparse_queries(synth.SEED_SPQUERY, 0, B, tabs)
+CUT = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # drop query terms more frequent than this rank
+if CUT:
+    rank = (qix.astype(np.int64) * pow(0x9E3779B1, -1, 1 << 31)) & 0x7FFFFFFF
+    keep = rank >= CUT
+    ip = np.zeros(B + 1, np.int64)
+    ip[1:] = np.cumsum([int(keep[qip[b]:qip[b + 1]].sum()) for b in range(B)])
+    qip, qix, qv = ip, qix[keep], qv[keep]
 t = [torch.from_numpy(a).cuda() for a in (qip, qix, qv)]
 for _ in range(2): ix.search_sparse(*t, 100)
 torch.cuda.synchronize()
