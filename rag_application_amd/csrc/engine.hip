@@ -101,6 +101,7 @@ struct hx_index {
   };
   SparseIx sp_base, sp_tail;
   int seg_docs_force = 0;             // HX_DEBUG_SEG_DOCS (tests): 32768 / 65536, 0 = by size
+  int sp_cut_step = 0;                // HX_DEBUG_SP_CUTSTEP (diagnostics): keys between cuts of the select pass, 0 = default
   int64_t tail_min_force = -1;        // HX_DEBUG_TAIL_MIN (tests): documents a tail may hold before the base is rebuilt
   float sp_wmin = 0.f, sp_wmax = 0.f; // range of the document weights (all finite: checked at ingest)
   bool sp_have_w = false;
@@ -789,6 +790,7 @@ static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* 
       a.part0 = v == 0 ? 0 : parts[0];
       a.cand = (uint64_t*)w.get(v == 0 ? WS_SP_CAND : WS_SP_PARK, (size_t)B * parts[v] * (ixs[v]->seg_docs + ixs[v]->seg_docs / 8) * 8);
       a.q_fail = fail;
+      a.cut_step = h->sp_cut_step;
       launch_sparse_select(a, st);
     }
   }
@@ -1102,6 +1104,7 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
     }
     h->psize[i] = msizes[i];
   }
+  if (const char* e = getenv("HX_DEBUG_SP_CUTSTEP")) h->sp_cut_step = std::max(0, atoi(e));
   if (const char* e = getenv("HX_DEBUG_SEG_DOCS")) {       // tests: force a segment size
     const int v = atoi(e);
     if (v == SEG_DOCS_SMALL || v == SEG_DOCS_LARGE) h->seg_docs_force = v;

@@ -225,6 +225,7 @@ struct SparseSelectArgs {
   int parts_total, part0;      // this launch writes parts [part0, part0 + parts) of every query
   uint64_t* cand;              // [B x parts x (seg_docs + seg_docs/8)] workgroup-private candidate buffers
   int* q_fail;                 // [B] set when a buffer overflowed: the query takes the exact path
+  int cut_step;                // keys the buffer grows by between cuts (0: max(1024, 4 * limit))
 };
 void launch_sparse_select(const SparseSelectArgs& a, hipStream_t st);   // dispatches on a.ix.seg_docs
 namespace v32k { void launch_sparse_select_variant(const SparseSelectArgs& a, hipStream_t st); }

@@ -71,6 +71,7 @@ constexpr int SP_WAVES = SP_THREADS / 64;
 #endif
 constexpr int SP_K = HX_SP_K;                // chunks per wave and visit held in registers
 constexpr int SP_CH = 128;                   // postings per chunk: two per lane
+constexpr int SP_KPT = 8;                    // keys per thread a cut holds in registers
 
 // Diagnostic build only (-DHX_SP_STAMP): lane 0 of waves 0 and 5 accumulate s_memtime deltas per phase of a
 // visit into a debug buffer of its own (never read by the kernel, never in a timed build).
@@ -78,10 +79,12 @@ constexpr int SP_CH = 128;                   // postings per chunk: two per lane
 __device__ unsigned long long g_sp_stamps[2 * 8 * 4096];
 #define SP_STAMP_DECL unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define SP_STAMP(i) { const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; }
+#define SP_STAMP_CUT st_acc[6] += 1ull << 40;
 #define SP_STAMP_FLUSH if ((tid == 0 || tid == 320) && blockIdx.x < 4096) for (int i_ = 0; i_ < 8; ++i_) g_sp_stamps[(blockIdx.x * 2 + (tid != 0)) * 8 + i_] = st_acc[i_];
 #else
 #define SP_STAMP_DECL
 #define SP_STAMP(i)
+#define SP_STAMP_CUT
 #define SP_STAMP_FLUSH
 #endif
 
@@ -92,11 +95,10 @@ struct SpShared {
   };
   int cnt;                                   // candidates in the workgroup's global buffer
   int ovf;                                   // an append found the buffer full
-  int redo;                                  // the register cut kept all 256: use the general cut
   uint32_t tau;                              // append threshold (integer score)
-  int n2;                                    // pre-filter: keys loaded into the sort scratch
-  uint32_t pre;                              // pre-filter threshold
-  uint32_t scan[HX_SP_THREADS];              // pre-filter: per-thread bin sums
+  int n2;                                    // cut: keys staged in the sort scratch
+  uint32_t pre;                              // cut: the new threshold
+  uint32_t scan[HX_SP_THREADS / 64];         // cut: per-wave histogram sums
   uint32_t otab[HX_SEG_DOCS == 65536 ? 6144 : 2560];   // run offsets of the query's terms for a window of segments
 };
 constexpr int SP_OT = HX_SEG_DOCS == 65536 ? 6144 : 2560;
@@ -130,156 +132,151 @@ __device__ __forceinline__ uint32_t sp_thr(uint32_t aL, int M) {
   return t < 1 ? 1u : (uint32_t)t;
 }
 
-// Sort the workgroup's candidate buffer (global) through LDS, keep {a >= thr(a_L)}, raise tau.
+// inclusive scan over the 64 lanes: four DPP row shifts (zeros shifted in), then the row totals
+// travel with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3)
+__device__ __forceinline__ uint32_t sp_wavescan(uint32_t v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xF, 0xF, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xF, 0xF, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xA, 0xF, false);   // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xC, 0xF, false);   // row_bcast:31
+  return v;
+}
+// Cut the workgroup's candidate buffer (global) to {a >= thr}, raise tau.  thr = (a lower bound of the L-th best
+// integer score) - M + 1.  No sort: the scores are 16-bit integers, so a histogram over the (all-zero) accumulator
+// -- bins of 2^SP_HSHIFT scores -- finds the bin of the L-th best, and the bin's lower edge stands for a_L (a lower
+// bound, so the kept set can only be larger; edges grow with a_L, so tau never falls).  The kept keys are staged
+// in LDS and written back as a prefix of the buffer.  final: they are also sorted best first -- the part's list
+// is consumed in that order (sprescore.hip); intermediate cuts need no order at all.
 // Precondition: acc is all zero and every wave is past its last acc access.
-__device__ __forceinline__ void sp_cut(uint64_t* cand, int limit, int M, int tid) {
+__device__ __forceinline__ void sp_cut(uint64_t* cand, int limit, int M, int tid, bool final) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's appends have left the core
   __syncthreads();                                   // ... and every other wave's; S.cnt settled
   int n = S.cnt;
   n = n < SP_GCAP ? n : SP_GCAP;
-  bool general = !(limit <= 256 && n <= SP_WAVES * 256);   // block-uniform
-  if (!general) {
-    // every wave sorts 256 keys in registers (wsort.hpp), then log2(SP_WAVES) pairwise folds through the
-    // sort scratch keep the best 256: one barrier per fold instead of one per bitonic stage
-    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint64_t v[4];
+  if (n < limit && !final) return;                   // block-uniform: no L-th best yet, every key stays
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int PER = SEG_WORDS / SP_THREADS;        // bins per thread
+  // the keys of this thread: i = tid + j * SP_THREADS; the first SP_KPT of them stay in registers across the
+  // passes below (a buffer of up to SP_KPT * SP_THREADS keys -- the usual case -- is read from memory once)
+  uint64_t kr[SP_KPT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = w * 256 + e * 64 + lane;
-      v[e] = i < n ? sp_ld_key(cand + i) : 0ull;
-    }
-    if (n > w * 256) w_sort<256>(v, lane);
-#pragma unroll
-    for (int s = 0; (1 << s) < SP_WAVES; ++s) {
-      const int m = (2 << s) - 1;
-      if ((w & m) == (1 << s)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) S.sort[w * 256 + lane * 4 + e] = v[e];
-      }
-      lds_barrier();   // (every wave's loads of cand were consumed by its sort: they precede wave 0's stores)
-      const int pw = w + (1 << s);
-      if ((w & m) == 0 && n > pw * 256) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = k64max(v[e], S.sort[pw * 256 + 255 - (lane * 4 + e)]);
-        w_merge<256, 128>(v, lane);
-      }
-    }
-    if (w == 0) {
-      uint32_t thr = 1;
-      if (n >= limit) {
-        const int kr = limit - 1;
-        const uint64_t mine = (kr & 3) == 0 ? v[0] : ((kr & 3) == 1 ? v[1] : ((kr & 3) == 2 ? v[2] : v[3]));
-        const uint64_t kth = (uint64_t)__shfl((unsigned long long)mine, kr >> 2, 64);
-        thr = sp_thr((uint32_t)(kth >> 32), M);
-      }
-      int nk = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) nk += __popcll(__ballot((uint32_t)(v[e] >> 32) >= thr));   // empty slots score 0
-      const bool cut_short = n > 256 && nk == 256;   // the 256 kept all pass: more may lie beyond
-      if (!cut_short) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if ((uint32_t)(v[e] >> 32) >= thr) sp_st_key(cand + lane * 4 + e, v[e]);   // sorted: a prefix
-        if (lane == 0) {
-          S.tau = thr;
-          S.cnt = nk;
-        }
-      }
-      if (lane == 0) S.redo = cut_short ? 1 : 0;
-    }
-    lds_barrier();     // every fold has read its partner's slice; S.redo is set
-    if (w != 0) {      // acc back to zero: each wave but 0 wrote its slice at most once
-#pragma unroll
-      for (int e = 0; e < 4; ++e) S.sort[w * 256 + lane * 4 + e] = 0ull;
-    }
-    general = S.redo != 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!general) return;
+  for (int j = 0; j < SP_KPT; ++j) {
+    const int i = tid + j * SP_THREADS;
+    kr[j] = i < n ? sp_ld_key(cand + i) : 0ull;
   }
-  // ---- general cut
-  uint32_t pre = 0;
-  if (n > SP_CAP) {
-    // More keys than the LDS can sort (the first visits of a dense query, before there is a threshold): the
-    // scores are 16-bit integers, so a histogram over the (all-zero) accumulator finds a lower bound of the
-    // L-th best score, and only the keys within the margin of THAT are sorted.
-    constexpr int PER = SEG_WORDS / SP_THREADS;      // bins per thread
-    for (int i = tid; i < n; i += SP_THREADS)
+  uint32_t thr = 1u;
+  if (n >= limit) {                                  // block-uniform
+#pragma unroll
+    for (int j = 0; j < SP_KPT; ++j)
+      if (tid + j * SP_THREADS < n)
+        __hip_atomic_fetch_add(&S.acc[(uint32_t)(kr[j] >> 32) >> SP_HSHIFT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int i = tid + SP_KPT * SP_THREADS; i < n; i += SP_THREADS)
       __hip_atomic_fetch_add(&S.acc[(uint32_t)(sp_ld_key(cand + i) >> 32) >> SP_HSHIFT], 1u, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_WORKGROUP);
     lds_barrier();
+    // thread t owns bins [t * PER, (t + 1) * PER) (read rotated: the lanes of a wave then hit different banks)
     uint32_t mine = 0;
 #pragma unroll 8
-    for (int j = 0; j < PER; ++j) mine += S.acc[tid * PER + j];
-    S.scan[tid] = mine;
+    for (int j = 0; j < PER; ++j) mine += S.acc[tid * PER + ((j + tid) & (PER - 1))];
+    const uint32_t incl = sp_wavescan(mine);
+    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (lane == 0) S.scan[w] = wtot;
     if (tid == 0) S.pre = 1u;
     lds_barrier();
-    uint32_t above = 0;                              // keys in the bins of the threads above this one
-    for (int t = tid + 1; t < SP_THREADS; ++t) above += S.scan[t];
+    uint32_t above = wtot - incl;                    // keys in the bins of the threads above this one
+    for (int x = w + 1; x < SP_WAVES; ++x) above += S.scan[x];
     if (above < (uint32_t)limit && above + mine >= (uint32_t)limit) {   // the L-th best key lies in this thread's bins
-      uint32_t run = above;
+      uint32_t bins[PER];                            // (one LDS round trip, not PER of them)
+#pragma unroll
+      for (int j = 0; j < PER; ++j) bins[j] = S.acc[tid * PER + j];
+      uint32_t run = above, edge = 0;
+      bool found = false;
+#pragma unroll
       for (int j = PER - 1; j >= 0; --j) {
-        run += S.acc[tid * PER + j];
-        if (run >= (uint32_t)limit) {
-          S.pre = sp_thr((uint32_t)(tid * PER + j) << SP_HSHIFT, M);   // lower edge of the bin: <= the true a_L
-          break;
+        run += bins[j];
+        if (!found && run >= (uint32_t)limit) {
+          found = true;
+          edge = (uint32_t)(tid * PER + j) << SP_HSHIFT;   // lower edge of the bin: <= the true a_L
         }
       }
+      S.pre = sp_thr(edge, M);
     }
     lds_barrier();
-    pre = S.pre;
-    for (int i = tid; i < SEG_WORDS; i += SP_THREADS) S.acc[i] = 0u;
-    if (tid == 0) S.n2 = 0;
-    lds_barrier();
-    for (int i = tid; i < n; i += SP_THREADS) {
-      const uint64_t k = sp_ld_key(cand + i);
-      if ((uint32_t)(k >> 32) >= pre) {
-        const int pos = atomicAdd(&S.n2, 1);
-        if (pos < SP_CAP) S.sort[pos] = k;
-      }
+    thr = S.pre;
+#pragma unroll
+    for (int j = 0; j < SP_KPT; ++j)
+      if (tid + j * SP_THREADS < n) S.acc[(uint32_t)(kr[j] >> 32) >> SP_HSHIFT] = 0u;
+    for (int i = tid + SP_KPT * SP_THREADS; i < n; i += SP_THREADS)
+      S.acc[(uint32_t)(sp_ld_key(cand + i) >> 32) >> SP_HSHIFT] = 0u;
+  }
+  if (tid == 0) S.n2 = 0;
+  lds_barrier();                                     // acc is all zero again: its words now stage the kept keys
+  auto stage = [&](bool p, uint64_t k) {             // called by whole waves
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+    if (m) {                                         // wave-uniform: one LDS atomic per wave
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&S.n2, __popcll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (p && pos < SP_CAP) S.sort[pos] = k;
     }
-    lds_barrier();
-    if (S.n2 > SP_CAP && tid == 0) S.ovf = 1;        // more keys within the margin than can be sorted: exact path
-    n = S.n2 < SP_CAP ? S.n2 : SP_CAP;
+  };
+#pragma unroll
+  for (int j = 0; j < SP_KPT; ++j)
+    if (j * SP_THREADS < n) stage(tid + j * SP_THREADS < n && (uint32_t)(kr[j] >> 32) >= thr, kr[j]);   // block-uniform guard
+  for (int i0 = SP_KPT * SP_THREADS; i0 < n; i0 += SP_THREADS) {   // (block-uniform trip count)
+    const int i = i0 + tid;
+    const uint64_t k = i < n ? sp_ld_key(cand + i) : 0ull;
+    stage(i < n && (uint32_t)(k >> 32) >= thr, k);
   }
-  int P = SP_THREADS;                                // sort size: next power of two >= n
-  while (P < n) P <<= 1;
-  if (!pre) {
-    for (int i = tid; i < P; i += SP_THREADS) S.sort[i] = i < n ? sp_ld_key(cand + i) : 0ull;
+  lds_barrier();                                     // (every read of cand above precedes the stores below)
+  int keep = S.n2;
+  if (keep > SP_CAP) {                               // more keys within the margin than the LDS can stage: exact path
+    if (tid == 0) S.ovf = 1;
+    keep = SP_CAP;
   }
-  lds_barrier();
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < P; i += SP_THREADS) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const uint64_t x = S.sort[i], y = S.sort[ixj];
-          const bool desc = (i & k) == 0;
-          if (desc ? (x < y) : (x > y)) {
-            S.sort[i] = y;
-            S.sort[ixj] = x;
-          }
-        }
+  if (final && keep > 1) {
+    if (keep <= 256) {                               // one wave, in registers (wsort.hpp): the usual case
+      if (w == 0) {
+        uint64_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = S.sort[lane * 4 + e];       // zero beyond `keep`
+        w_sort<256>(v, lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S.sort[lane * 4 + e] = v[e];
       }
       lds_barrier();
+    } else {
+      int P = 512;                                   // sort size: next power of two >= keep (zeros beyond it)
+      while (P < keep) P <<= 1;
+      for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = tid; i < P; i += SP_THREADS) {
+            const int ixj = i ^ j;
+            if (ixj > i) {
+              const uint64_t x = S.sort[i], y = S.sort[ixj];
+              const bool desc = (i & k) == 0;
+              if (desc ? (x < y) : (x > y)) {
+                S.sort[i] = y;
+                S.sort[ixj] = x;
+              }
+            }
+          }
+          lds_barrier();
+        }
+      }
     }
+  }
+  for (int i = tid; i < keep; i += SP_THREADS) {
+    sp_st_key(cand + i, S.sort[i]);
+    S.sort[i] = 0ull;                                // acc back to zero
   }
   if (tid == 0) {
-    uint32_t thr = 1;
-    if (n >= limit) thr = sp_thr((uint32_t)(S.sort[limit - 1] >> 32), M);
-    int lo = 0, hi = n;                              // first index whose score is below thr (descending list)
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((uint32_t)(S.sort[mid] >> 32) >= thr) lo = mid + 1; else hi = mid;
-    }
     S.tau = thr;
-    S.cnt = lo;
+    S.cnt = keep;
   }
-  lds_barrier();
-  const int keep = S.cnt;
-  for (int i = tid; i < keep; i += SP_THREADS) sp_st_key(cand + i, S.sort[i]);
-  lds_barrier();
-  for (int i = tid; i < P; i += SP_THREADS) S.sort[i] = 0ull;   // acc back to zero
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
@@ -313,17 +310,6 @@ __device__ __forceinline__ void sp_append2(uint64_t* cand, bool p0, uint32_t a0,
 struct SpDir {            // lane = term slot
   uint32_t p0, len, incl;  // first posting / postings / inclusive chunk count up to this term
 };
-// inclusive scan over the 64 lanes: four DPP row shifts (zeros shifted in), then the row totals
-// travel with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3)
-__device__ __forceinline__ uint32_t sp_wavescan(uint32_t v) {
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xF, 0xF, true);    // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xF, 0xF, true);    // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xF, 0xF, true);    // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xF, 0xF, true);    // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xA, 0xF, false);   // row_bcast:15
-  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xC, 0xF, false);   // row_bcast:31
-  return v;
-}
 __device__ __forceinline__ SpDir sp_dir(uint32_t p0, uint32_t p1, bool active, uint32_t& nch) {
   SpDir d;
   d.p0 = p0;
@@ -447,7 +433,6 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
   if (tid == 0) {
     S.cnt = 0;
     S.ovf = 0;
-    S.redo = 0;
     S.tau = 1u;
   }
   // term slot: table row and scaled query weight (absent terms and unused slots are inactive)
@@ -649,20 +634,24 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
       continue;
     }
     // cut (acc is all zero between visits; it drains the loads in flight); the last one gives the part's list
-    sp_cut(cand, a.limit, M, tid);
+    SP_STAMP(0)
+    sp_cut(cand, a.limit, M, tid, seg >= s1);
+    SP_STAMP(6)
+    SP_STAMP_CUT
     if (seg >= s1) break;
     {                                                   // later cuts: when the buffer has grown by a few lists
       const int c = __builtin_amdgcn_readfirstlane(S.cnt);
-      const int t = c + (4 * a.limit < 1024 ? 1024 : 4 * a.limit);
+      const int t = c + (a.cut_step > 0 ? a.cut_step : (4 * a.limit < 1024 ? 1024 : 4 * a.limit));
       trig_r = t < SP_CAP * 3 / 4 ? t : SP_CAP * 3 / 4;
       ub = (uint32_t)c;
     }
   }
-  SP_STAMP_FLUSH
   // ---- the part's list: the kept keys (best first)
   const int nk = S.cnt;
   const int n = nk < a.lout ? nk : a.lout;
   for (int i = tid; i < a.lout; i += SP_THREADS) o[i] = i < n ? sp_ld_key(cand + i) : 0ull;
+  SP_STAMP(7)
+  SP_STAMP_FLUSH
   if (tid == 0) {
     *ocnt = n;
     if (nk > a.lout || S.ovf) a.q_fail[q] = 1;          // cut short: the query takes the exact path

@@ -29,9 +29,13 @@ buf = np.zeros(2 * 8 * 1024, np.uint64)
 _lib.lib().hx_debug_sp_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rc = _lib.lib().hx_debug_sp_stamps(buf.ctypes.data, 2 * 8 * 1024); assert rc == 0
 st = buf.reshape(1024, 2, 8).astype(np.float64)
-names = ["loop+cut check", "dir+issue(s+2)", "offsets+accumulate", "barrier X", "harvest", "barrier Y"]
+names = ["loop+cut check", "dir+issue(s+2)", "offsets+accumulate", "barrier X", "harvest", "barrier Y", "cuts (sort + threshold)", "output"]
+raw = buf.reshape(1024, 2, 8)
+cuts = (raw[:, 0, 6] >> np.uint64(40)).astype(np.float64)
+st[:, :, 6] = (raw[:, :, 6] & np.uint64((1 << 40) - 1)).astype(np.float64)
+print("cuts per workgroup: mean %.1f  p10 %.0f  p90 %.0f  max %.0f;  cycles per cut %.0f" % (cuts.mean(), np.percentile(cuts, 10), np.percentile(cuts, 90), cuts.max(), st[:, 0, 6].sum() / max(cuts.sum(), 1)))
 for w, wn in ((0, "wave 0"), (1, "wave 5")):
-    s = st[:, w, :6]
+    s = st[:, w, :8]
     tot = s.sum(1)
     print(wn, "cycles per visit: mean %.0f  p50 %.0f  max %.0f  (s_memtime = shader cycles)" % (tot.mean() / nseg, np.median(tot) / nseg, tot.max() / nseg))
     for i, n in enumerate(names):
