@@ -623,9 +623,10 @@ def test_sparse_select_paths(eng, torch_mod, monkeypatch, seg_docs):
 def test_sparse_cut_partial_slices(eng, torch_mod, monkeypatch, seg_docs):
     """The candidate cut of k_sparse_select with the buffer ending at every position of the waves' 256-key
     slices: term k is held by exactly n_k documents of ONE segment, so the only visit appends n_k candidates
-    and the final cut sorts exactly n_k keys -- n_k = 256 w + r across the register cut (up to waves x 256
-    keys), the general LDS sort beyond it, and the histogram pre-filter once n_k exceeds what the LDS sorts
-    (seg_docs / 4 keys)."""
+    and the final cut works on exactly n_k keys -- fewer than the limit (no threshold), n_k = 256 w + r around
+    every multiple of a wave's share, more keys than a thread keeps in registers (8 x threads: the passes
+    re-read the rest from memory), and kept sets on both sides of 256 (one wave sorts the final list in
+    registers / the LDS bitonic network: limits 10, 100, 256 and 300)."""
     monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
     n, dim = 30000, 64
     counts = [1, 63, 64, 65, 100, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1500,
