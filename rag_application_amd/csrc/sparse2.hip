@@ -445,7 +445,7 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
   const bool active = ti >= 0;
   const uint2* post = a.ix.post;
   // The run offsets (table rows of the query's terms) live in LDS for a window of W1 consecutive segments: one
-  // coalesced fill by the whole workgroup every W1 - 3 visits instead of two 64-line gathers per wave and visit
+  // coalesced fill by the whole workgroup every W1 - 4 visits instead of two 64-line gathers per wave and visit
   // -- and no table load queued in front of the posting loads any more.  Entry (t, x) = first posting of term
   // t in segment x or later (x clamped to the end of the term's postings).
   const int Tn = T < SP_TMAX ? T : SP_TMAX;
@@ -481,9 +481,8 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
     uint32_t mask;           // 2 bits per slot: which of the lane's two postings count
     uint32_t tpack;          // scalar: 6 bits per slot, the term slot of the chunk; bit 24 + k: slot k is a full chunk
   };
-  auto issue = [&](Stage& st, int x, bool on) {        // directory of segment x from the table, then the posting loads
-    uint32_t olo, ohi;
-    offs(x, olo, ohi);
+  // (olo, ohi): the lane's run in the segment, read from the window table a visit earlier
+  auto issue = [&](Stage& st, uint32_t olo, uint32_t ohi, bool on) {   // directory of the segment, then the posting loads
     const SpDir sd = sp_dir(olo, ohi, active && on, st.nch);
     st.mask = 0;
     st.tpack = 0;
@@ -504,9 +503,12 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
   };
   // one visit on stage `cur`; `nx` = stage(seg + 2).  Returns the chunks of the NEXT visit's segment.
   SP_STAMP_DECL
+  uint32_t tau_r = 1u;      // S.tau in a scalar register: it changes at cuts only
+  uint32_t nlo = 0, nhi = 0;   // the lane's run offsets of segment seg + 2 at the top of visit(seg)
   auto visit = [&](Stage& cur, Stage& nx, const Stage& nx1, int seg, uint32_t& appended_max) {
     SP_STAMP(0)                                         // loop control, cut check
-    issue(nx, seg + 2, seg + 2 < s1);                   // postings of seg + 2: two visits ahead
+    issue(nx, nlo, nhi, seg + 2 < s1);                  // postings of seg + 2: two visits ahead
+    offs(seg + 3, nlo, nhi);                            // (consumed by the next visit: no LDS round trip at its top)
     SP_STAMP(1)
     const uint32_t nch = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.nch);
     appended_max = nch * SP_CH < (uint32_t)SEG_DOCS ? nch * SP_CH : (uint32_t)SEG_DOCS;
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
       const uint32_t tpack = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.tpack);
       const uint32_t mask = cur.mask;
       const uint32_t gbase = (uint32_t)(a.ix.id_base + (int64_t)seg * SEG_DOCS);
-      const uint32_t tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.tau);
+      const uint32_t tau = tau_r;
 #pragma unroll
       for (int k = 0; k < SP_K; ++k)
         sp_accumulate(cur.p[k], (mask >> (2 * k)) & 3u, sp_lane_f(qs_lane, (int)((tpack >> (6 * k)) & 63u)),
@@ -605,14 +607,20 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
     st2.tpack = 0;
 #pragma unroll
     for (int k = 0; k < SP_K; ++k) st2.p[k] = make_uint4(0, 0, 0, 0);
-    issue(st0, seg, seg < s1);
-    issue(st1, seg + 1, seg + 1 < s1);
+    {
+      uint32_t a0, a1, b0, b1;
+      offs(seg, a0, a1);
+      offs(seg + 1, b0, b1);
+      offs(seg + 2, nlo, nhi);
+      issue(st0, a0, a1, seg < s1);
+      issue(st1, b0, b1, seg + 1 < s1);
+    }
     // Visits until the candidate buffer has to be cut, or the range ends.  The body is three visits in a fixed
     // rotation of the stages -- straight-line, so that a stage is the same registers on every trip and the
     // loads in flight are never copied (a stage picked by a branch made hipcc copy all three at the loop
     // header, behind a vmcnt(0): no prefetch at all).
     bool cut = false;
-    const int wend = w0 + W1 - 4;                       // last segment whose visit finds seg + 3 inside the window
+    const int wend = w0 + W1 - 5;                       // last segment whose visit finds seg + 3 (and its end) inside the window
     for (;;) {
       uint32_t am, nn;
       if (seg >= s1 || seg > wend) break;
@@ -636,6 +644,7 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
     // cut (acc is all zero between visits; it drains the loads in flight); the last one gives the part's list
     SP_STAMP(0)
     sp_cut(cand, a.limit, M, tid, seg >= s1);
+    tau_r = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.tau);
     SP_STAMP(6)
     SP_STAMP_CUT
     if (seg >= s1) break;
