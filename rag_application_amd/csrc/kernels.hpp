@@ -178,7 +178,8 @@ constexpr int SP_TMAX = 64;            // query terms the select pass takes (one
 // Term-major inverted index over the documents [doc0, doc0 + n_docs) of the shard: the postings of live
 // term i (ascending document) are post[ptr[i*(n_segments+1) + 0] .. ptr[i*(n_segments+1) + n_segments]);
 // ptr[i*(S+1) + s] is the first posting of term i whose document lies in segment s or later.  A posting
-// is {document index inside its segment, fp32 weight bits}.
+// is {the document's place in the select pass's accumulator: byte offset of its 32-bit LDS word (document index
+// inside the segment mod seg_docs/2, times 4) | shift of its 16-bit half (0 / 16) << 24, fp32 weight bits}.
 struct SparseIndexView {
   const uint2* post;           // [nnz] (+ 16 bytes of padding)
   const uint32_t* ptr;         // [n_live x (n_segments + 1)]

@@ -16,8 +16,8 @@
 // document with a > a_L - M: a superset of the exact top-L whose size is L plus the few documents
 // within M units of the L-th.
 //
-// Index layout (spbuild.hip): TERM-major postings sorted by (term, document) as {document index inside
-// its segment, fp32 weight}; documents are cut into segments of SEG_DOCS and a dense table gives, for
+// Index layout (spbuild.hip): TERM-major postings sorted by (term, document) as {place of the document's
+// accumulator inside its segment (sp_word below), fp32 weight}; documents are cut into segments of SEG_DOCS and a dense table gives, for
 // every live term and segment, the offset of the term's first posting in that segment or later.
 //
 // One workgroup owns (query, part): a contiguous range of segments and an LDS accumulator of one 16-bit
@@ -338,7 +338,7 @@ struct __attribute__((aligned(8))) SpPair { uint32_t x, y, z, w; };
 __device__ __forceinline__ uint4 sp_load2(const uint2* post, uint32_t off, uint32_t cnt, int lane) {
   const uint32_t i = (uint32_t)(2 * lane) < cnt ? (uint32_t)(2 * lane) : 0u;   // (the array is padded by one posting)
 #if HX_SP_EXP == 4      // timing experiment: no posting loads at all
-  return make_uint4((off + i) & 0xFFFFu, 0x3f800000u, (off + i + 1) & 0xFFFFu, 0x3f800000u);
+  return make_uint4(((off + i) & 0x7FFFu) << 2, 0x3f800000u, ((off + i + 1) & 0x7FFFu) << 2, 0x3f800000u);
 #elif HX_SP_EXP == 5    // timing experiment: 16-byte aligned loads (reads the wrong pair for odd offsets)
   return *(const uint4*)(post + ((off + i) & ~1u));
 #endif
@@ -348,14 +348,20 @@ __device__ __forceinline__ uint4 sp_load2(const uint2* post, uint32_t off, uint3
 __device__ __forceinline__ uint32_t sp_units(uint32_t wbits, float qs) {
   return (uint32_t)__fmul_rn(__builtin_bit_cast(float, wbits), qs) + 1u;       // trunc(w * qs) + 1
 }
-__device__ __forceinline__ void sp_add1(uint32_t doc, uint32_t v) {
+// A posting's first word (spbuild.hip: k_make_postings) is the document's place in the accumulator, ready to use:
+// bits 0-23 the BYTE offset of its 32-bit word (document index mod SEG_WORDS, times 4), bits 24-28 the shift of
+// its 16-bit half inside the word (0 or 16) -- no index arithmetic per posting in the kernel.
+__device__ __forceinline__ uint32_t* sp_word(uint32_t e) { return (uint32_t*)((char*)S.acc + (e & 0xFFFFFFu)); }
+__device__ __forceinline__ uint32_t sp_doc(uint32_t e) {          // document index inside the segment (appends only)
+  return ((e & 0xFFFFFFu) >> 2) | ((e >> 28) << SEG_WSHIFT);
+}
+__device__ __forceinline__ void sp_add1(uint32_t e, uint32_t v) {
 #if HX_SP_EXP == 6      // timing experiment: no LDS traffic at all
-  asm volatile("" ::"v"(v << ((doc >> SEG_WSHIFT) << 4)), "v"(doc & (SEG_WORDS - 1)));
+  asm volatile("" ::"v"(v << (e >> 24)), "v"(e & 0xFFFFFFu));
 #elif HX_SP_EXP == 2 || HX_SP_EXP == 3
-  S.acc[doc & (SEG_WORDS - 1)] = v << ((doc >> SEG_WSHIFT) << 4);
+  *sp_word(e) = v << (e >> 24);
 #else
-  __hip_atomic_fetch_add(&S.acc[doc & (SEG_WORDS - 1)], v << ((doc >> SEG_WSHIFT) << 4), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_fetch_add(sp_word(e), v << (e >> 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 }
 // m: bit 0 / bit 1 = the lane's first / second posting counts
@@ -372,18 +378,17 @@ __device__ __forceinline__ void sp_accumulate(const uint4& p, uint32_t m, float 
     if (m & 2u) sp_add1(p.z, sp_units(p.w, qs));
   }
 }
-__device__ __forceinline__ uint32_t sp_take1(uint32_t doc) {
-  const uint32_t sh = (doc >> SEG_WSHIFT) << 4;
+__device__ __forceinline__ uint32_t sp_take1(uint32_t e) {
+  const uint32_t sh = e >> 24;
 #if HX_SP_EXP == 6
-  return (doc >> 31) + (sh >> 8);
+  return (e >> 31) + (sh >> 8);
 #endif
 #if HX_SP_EXP == 1 || HX_SP_EXP == 3
-  const uint32_t o = S.acc[doc & (SEG_WORDS - 1)];
-  ((uint16_t*)&S.acc[doc & (SEG_WORDS - 1)])[doc >> SEG_WSHIFT] = 0;
+  const uint32_t o = *sp_word(e);
+  ((uint16_t*)sp_word(e))[sh >> 4] = 0;
   return (o >> sh) & 0xFFFFu;
 #endif
-  const uint32_t old = __hip_atomic_fetch_and(&S.acc[doc & (SEG_WORDS - 1)], ~(0xFFFFu << sh), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint32_t old = __hip_atomic_fetch_and(sp_word(e), ~(0xFFFFu << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return (old >> sh) & 0xFFFFu;
 }
 __device__ __forceinline__ void sp_harvest(const uint4& p, uint32_t m, uint64_t* cand, uint32_t tau, uint32_t gbase,
@@ -396,7 +401,7 @@ __device__ __forceinline__ void sp_harvest(const uint4& p, uint32_t m, uint64_t*
     if (m & 1u) a0 = sp_take1(p.x);
     if (m & 2u) a1 = sp_take1(p.z);
   }
-  sp_append2(cand, a0 >= tau, a0, gbase + p.x, a1 >= tau, a1, gbase + p.z);   // tau >= 1: a cleared half never passes
+  sp_append2(cand, a0 >= tau, a0, gbase + sp_doc(p.x), a1 >= tau, a1, gbase + sp_doc(p.z));   // tau >= 1: a cleared half never passes
 }
 
 // ---------------------------------------------------------------------------------

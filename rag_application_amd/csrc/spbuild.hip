@@ -47,12 +47,15 @@ __global__ void k_make_pairs(const int64_t* indptr, const int32_t* idx, const fl
   }
 }
 
-// sorted payloads -> postings {document index inside its segment, weight bits}
+// sorted payloads -> postings {accumulator place of the document inside its segment, weight bits}
 __global__ void k_make_postings(const uint64_t* pay, int64_t nnz, uint32_t seg_docs, uint2* post) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
   const uint64_t p = pay[i];
-  post[i] = make_uint2((uint32_t)(p >> 32) % seg_docs, (uint32_t)p);
+  // first word: where the document's 16-bit accumulator lives in the select pass's LDS (sparse2.hip: sp_word) --
+  // byte offset of its 32-bit word (document mod seg_docs/2, times 4) | shift of its half (0 / 16) << 24
+  const uint32_t d = (uint32_t)(p >> 32) % seg_docs, words = seg_docs >> 1;
+  post[i] = make_uint2(((d & (words - 1)) << 2) | (d >= words ? 16u << 24 : 0u), (uint32_t)p);
 }
 
 // one workgroup per live term: ptr[t][s] = first posting of the term's run [b, e) whose document
