@@ -54,7 +54,7 @@ enum WsSlot {
   WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT, WS_KEPT,
   WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC,
   WS_SP_TI0, WS_SP_TI1, WS_SP_QS, WS_SP_MARGIN, WS_SP_FLAG, WS_SP_WORK, WS_SP_FAIL, WS_SP_LIST, WS_SP_LCNT,
-  WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF, WS_SP_QPARTS
+  WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF, WS_SP_QPARTS, WS_SP_SUM
 };
 
 template <typename T>
@@ -117,6 +117,12 @@ struct hx_index {
   std::vector<ProfRec> prof_recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
   unsigned long long* sp_counter = nullptr;   // postings of the queries' terms (k_sparse_prep) while profiling
+  // One host round trip per batch for all the stages' failure flags: the small counters travel into this pinned
+  // buffer ([0] a dense stage's failure count, [1..2] the sparse stage's summary) behind ONE synchronisation.
+  int* pin = nullptr;
+  bool sp_sum_pending = false;        // a sparse_enqueue's summary has not been consumed by sparse_resolve yet
+  bool sp_sum_fetched = false;        // ... and is already in sp_sum (a dense stage's flag read took it along)
+  int sp_sum[2] = {0, 0};             // flagged-or-failed queries, any invalid query
 
   void set_device() const { HX_HIP(hipSetDevice(device)); }
 };
@@ -517,10 +523,24 @@ static void exact_range_fallback(hx_index* h, int kind, const void* M, int64_t r
   }
 }
 
+static int* host_pin(hx_index* h) {
+  if (!h->pin) HX_HIP(hipHostMalloc((void**)&h->pin, 64, hipHostMallocDefault));
+  return h->pin;
+}
+
 static std::vector<int> read_failures(hx_index* h, int* fail, int* nfail, int B, hipStream_t st) {
-  int nf = 0;
-  HX_HIP(hipMemcpyAsync(&nf, nfail, 4, hipMemcpyDeviceToHost, st));
+  int* pin = host_pin(h);
+  HX_HIP(hipMemcpyAsync(pin, nfail, 4, hipMemcpyDeviceToHost, st));
+  // a sparse stage enqueued before this point (search_dense's `between`): its summary rides along
+  const bool take_sparse = h->sp_sum_pending && !h->sp_sum_fetched;
+  if (take_sparse) HX_HIP(hipMemcpyAsync(pin + 1, h->ws.get(WS_SP_SUM, 8), 8, hipMemcpyDeviceToHost, st));
   HX_HIP(hipStreamSynchronize(st));
+  const int nf = pin[0];
+  if (take_sparse) {
+    h->sp_sum[0] = pin[1];
+    h->sp_sum[1] = pin[2];
+    h->sp_sum_fetched = true;
+  }
   std::vector<int> sel;
   if (nf > 0) {
     std::vector<int> f((size_t)B);
@@ -821,6 +841,9 @@ static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* 
   ra.q_fail = fail;
   launch_sparse_rescore(ra, st);
   launch_compact(ra.out, lout, ra.out_cnt, B, std::min(L, lout), 0, out_keys, L, out_cnt, nullptr, lout, st);
+  launch_sparse_summary(flag, fail, B, (int*)w.get(WS_SP_SUM, 8), st);
+  h->sp_sum_pending = true;
+  h->sp_sum_fetched = false;
 }
 
 // Document-at-a-time path for the listed queries: every row through the exact arithmetic.  Rows are taken in
@@ -906,6 +929,16 @@ static void sparse_exact_fallback(hx_index* h, const int64_t* q_indptr, const in
 static bool sparse_resolve(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val, int B,
                            int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
   if (h->sp_base.n_segments == 0 && h->sp_tail.n_segments == 0) return false;
+  if (!h->sp_sum_fetched) {             // no dense stage read it along: one round trip of its own
+    int* pin = host_pin(h);
+    HX_HIP(hipMemcpyAsync(pin + 1, h->ws.get(WS_SP_SUM, 8), 8, hipMemcpyDeviceToHost, st));
+    HX_HIP(hipStreamSynchronize(st));
+    h->sp_sum[0] = pin[1];
+    h->sp_sum[1] = pin[2];
+  }
+  h->sp_sum_pending = false;
+  h->sp_sum_fetched = false;
+  if (h->sp_sum[0] == 0 && h->sp_sum[1] == 0) return false;      // the usual case: nothing flagged
   std::vector<int> flag((size_t)B), fail((size_t)B);
   HX_HIP(hipMemcpyAsync(flag.data(), h->ws.get(WS_SP_FLAG, (size_t)B * 4), (size_t)B * 4, hipMemcpyDeviceToHost, st));
   HX_HIP(hipMemcpyAsync(fail.data(), h->ws.get(WS_SP_FAIL, (size_t)B * 4), (size_t)B * 4, hipMemcpyDeviceToHost, st));
@@ -1130,6 +1163,7 @@ int hx_destroy(hx_index* h) {
                   h->sp_indptr, h->sp_idx, h->sp_val, h->sp_counter};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->pin) (void)hipHostFree(h->pin);
   h->ws.release();
   delete h;
   HX_CATCH

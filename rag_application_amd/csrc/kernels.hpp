@@ -229,6 +229,7 @@ struct SparseSelectArgs {
   int cut_step;                // keys the buffer grows by between cuts (0: max(1024, 4 * limit))
 };
 void launch_sparse_select(const SparseSelectArgs& a, hipStream_t st);   // dispatches on a.ix.seg_docs
+void launch_sparse_summary(const int* flag, const int* fail, int B, int* out, hipStream_t st);
 namespace v32k { void launch_sparse_select_variant(const SparseSelectArgs& a, hipStream_t st); }
 namespace v64k { void launch_sparse_select_variant(const SparseSelectArgs& a, hipStream_t st); }
 // q_parts[q] in [1, pt_max]: workgroups the query is cut into; items[0, *n_items): query << 8 | part, heaviest first

@@ -256,6 +256,33 @@ void launch_sparse_rescore(const SparseRescoreArgs& a, hipStream_t st) {
   HX_HIP(hipGetLastError());
 }
 
+// what the host needs to know about a batch's sparse flags in 8 bytes: out[0] = queries flagged for (or failed
+// into) the document-at-a-time path, out[1] = queries with a non-finite weight
+__global__ __launch_bounds__(256) void k_sparse_summary(const int* flag, const int* fail, int B, int* out) {
+  __shared__ int s_bad, s_inv;
+  if (threadIdx.x == 0) {
+    s_bad = 0;
+    s_inv = 0;
+  }
+  __syncthreads();
+  int bad = 0, inv = 0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    bad += (flag[b] != 0 || fail[b] != 0) ? 1 : 0;
+    inv += flag[b] == 2 ? 1 : 0;
+  }
+  if (bad) atomicAdd(&s_bad, bad);
+  if (inv) atomicAdd(&s_inv, inv);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = s_bad;
+    out[1] = s_inv;
+  }
+}
+void launch_sparse_summary(const int* flag, const int* fail, int B, int* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_sparse_summary, dim3(1), dim3(256), 0, st, flag, fail, B, out);
+  HX_HIP(hipGetLastError());
+}
+
 // the parts' lists of a query (each best first, `lout` slots, zeros after its count) -> one packed run + count
 __global__ __launch_bounds__(256) void k_sparse_pack(const uint64_t* parts, const int* pcnt, int pt, int lout,
                                                      uint64_t* out, int* out_cnt) {
