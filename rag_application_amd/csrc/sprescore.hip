@@ -178,27 +178,36 @@ __device__ __forceinline__ float sp_exact_score(const SparseCsr& d, int64_t doc,
   // the document's first 128 terms live in registers; longer documents re-read the rest per query term
   const int32_t i0 = b + lane < e ? d.idx[b + lane] : -1;
   const int32_t i1 = b + 64 + lane < e ? d.idx[b + 64 + lane] : -1;
+  // ... and so do their weights: a matched term's weight is a lane read, not another trip to memory behind the match
+  const float w0 = b + lane < e ? d.val[b + lane] : 0.0f;
+  const float w1 = b + 64 + lane < e ? d.val[b + 64 + lane] : 0.0f;
   float acc = 0.0f;
   any = false;
   for (int t = 0; t < T; ++t) {
     const int32_t term = q_idx[qb + t];
-    int64_t pos = -1;
+    bool hit = false;
+    float w = 0.0f;
     unsigned long long m = __ballot(i0 == term);
-    if (m) pos = b + __builtin_ctzll(m);
-    else {
+    if (m) {
+      hit = true;
+      w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w0), __builtin_ctzll(m)));
+    } else {
       m = __ballot(i1 == term);
-      if (m) pos = b + 64 + __builtin_ctzll(m);
-      else
+      if (m) {
+        hit = true;
+        w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w1), __builtin_ctzll(m)));
+      } else
         for (int64_t c = b + 128; c < e; c += 64) {
           m = __ballot(c + lane < e && d.idx[c + lane] == term);
           if (m) {
-            pos = c + __builtin_ctzll(m);
+            hit = true;
+            w = d.val[c + __builtin_ctzll(m)];
             break;
           }
         }
     }
-    if (pos >= 0) {                                  // wave-uniform
-      acc = __fadd_rn(acc, __fmul_rn(q_val[qb + t], d.val[pos]));
+    if (hit) {                                       // wave-uniform
+      acc = __fadd_rn(acc, __fmul_rn(q_val[qb + t], w));
       any = true;
     }
   }
