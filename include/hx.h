@@ -165,10 +165,20 @@ int hx_merge(int32_t device, const uint64_t* in_keys_dev, int32_t stride, const 
  *               0 = empty slot, ids are global: id_base + row);
  *  hx_h1_fuse   gathered_dev [world x B x (dense_limit + sparse_limit)] (rank-major, as
  *               all_gather_into_tensor leaves it): per query the global dense and sparse
- *               lists (top of the union of the shards' lists), then RRF as hx_rrf. */
+ *               lists (top of the union of the shards' lists), then RRF as hx_rrf;
+ *  hx_h1_local_async  hx_h1_local without its host round trip: everything is enqueued and the
+ *               call returns; keys_dev is [(B + 1) x (dense_limit + sparse_limit)], row B holds
+ *               in element 0 the number of queries whose lists are NOT final (a stage flagged
+ *               them for a retry or the exact path) and zeros after it.  The caller reads that
+ *               word when it suits it (it travels through the exchange with the lists, so every
+ *               rank sees every rank's word) and redoes the batch through hx_h1_local when any
+ *               rank's word is not zero.  Keeps consecutive batches back to back on the device. */
 int hx_h1_local(hx_index* h, const float* q_dev, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
                 const float* q_val_dev, int32_t B, int32_t dense_limit, int32_t sparse_limit,
                 uint64_t* keys_dev, void* stream);
+int hx_h1_local_async(hx_index* h, const float* q_dev, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
+                      const float* q_val_dev, int32_t B, int32_t dense_limit, int32_t sparse_limit,
+                      uint64_t* keys_dev, void* stream);
 int hx_h1_fuse(int32_t device, const uint64_t* gathered_dev, int32_t world, int32_t B,
                int32_t dense_limit, int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base,
                uint64_t* keys_dev, int32_t* counts_dev, void* stream);

@@ -68,6 +68,7 @@ _SIGS = {
                C.c_int32, _P, _P, _P],
     "hx_merge": [C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P],
     "hx_h1_local": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P],
+    "hx_h1_local_async": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P],
     "hx_h1_fuse": [C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                    _P, _P, _P],
     "hx_unpack": [C.c_int32, _P, C.c_int64, _P, _P, _P],

@@ -581,9 +581,11 @@ static void retry_subset(hx_index* h, const float* q_dev, const std::vector<int>
 // the host reads the failure flags -- so the device has work while the host waits, and the stream is
 // still full when it returns.  It may consume out_keys speculatively: the return value says whether a
 // retry or the exact path rewrote rows of out_keys after `between` ran (then the caller redoes it).
+// `defer`: enqueue only -- no flag read, no retry; the stage's failure count stays in WS_NFAIL (level 0) for
+// the caller (hx_h1_local_async), who redoes the batch through the synchronous path if it is not zero.
 static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int L, uint64_t* out_keys,
                          int* out_cnt, hipStream_t st, int level = 0,
-                         const std::function<void()>& between = std::function<void()>()) {
+                         const std::function<void()>& between = std::function<void()>(), bool defer = false) {
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   if (h->n == 0) {
@@ -630,6 +632,7 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
     launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st);
     if (between) between();
+    if (defer) return false;
     sel = read_failures(h, fail, nfail, B, st);
     if (!sel.empty() && level == 0) {
       retry_subset(h, q_dev, sel, L, out_keys, out_cnt, st, level,
@@ -642,6 +645,10 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     sel.resize((size_t)B);
     std::iota(sel.begin(), sel.end(), 0);
     if (between) between();
+    if (defer) {                         // no fp16 copy to scan: every query needs the exact path
+      launch_fill_i32(nfail, 1, B, st);
+      return false;
+    }
   }
   if (!sel.empty()) {
     h->dense_fallbacks += (int64_t)sel.size();
@@ -1498,6 +1505,32 @@ int hx_h1_local(hx_index* h, const float* qd, const int64_t* qip, const int32_t*
   });
   const bool sp_patched = sparse_resolve(h, qip, qix, qv, B, sparse_limit, S, Sc, st);
   if (patched || sp_patched) pack();
+  HX_CATCH
+}
+
+int hx_h1_local_async(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix, const float* qv, int32_t B,
+                      int32_t dense_limit, int32_t sparse_limit, uint64_t* keys_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && qd && qip && keys_dev && B > 0, "bad argument");
+  h->set_device();
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& w = h->ws;
+  const int L2 = dense_limit + sparse_limit;
+  uint64_t* D = (uint64_t*)w.get(WS_T_A, (size_t)B * dense_limit * 8);
+  int* Dc = (int*)w.get(WS_T_ACNT, (size_t)B * 4);
+  uint64_t* S = (uint64_t*)w.get(WS_T_B, (size_t)B * sparse_limit * 8);
+  int* Sc = (int*)w.get(WS_T_BCNT, (size_t)B * 4);
+  int* nfail = (int*)w.get(WS_NFAIL, 4);
+  int* spsum = (int*)w.get(WS_SP_SUM, 8);
+  HX_HIP(hipMemsetAsync(nfail, 0, 4, st));         // (an empty shard enqueues neither stage)
+  HX_HIP(hipMemsetAsync(spsum, 0, 8, st));
+  search_dense(h, qd, B, 0, dense_limit, D, Dc, st, 0, [&]() {
+    sparse_enqueue(h, qip, qix, qv, B, sparse_limit, S, Sc, st);
+    launch_concat(D, dense_limit, Dc, S, sparse_limit, Sc, B, keys_dev, st);
+  }, true);
+  h->sp_sum_pending = false;                       // nobody will call sparse_resolve for this batch
+  h->sp_sum_fetched = false;
+  launch_flag_row(nfail, spsum, keys_dev + (size_t)B * L2, L2, st);
   HX_CATCH
 }
 

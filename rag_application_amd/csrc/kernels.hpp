@@ -133,6 +133,7 @@ void launch_regroup(const uint64_t* g, int world, int B, int dl, int sl, uint64_
 void launch_scan_init(float* tau, int* cnt, int* ovf, int* kept, int B, int cnt0, hipStream_t st);
 void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st);
+void launch_flag_row(const int* nfail, const int* spsum, uint64_t* row, int len, hipStream_t st);
 
 // ---- prep.hip ----------------------------------------------------------------
 // Derive the stored vectors of rows [0,n) of `raw` (fp32 [n x dim]):

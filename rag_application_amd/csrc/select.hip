@@ -484,6 +484,16 @@ void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
   hipLaunchKernelGGL(k_fill<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
   HX_HIP(hipGetLastError());
 }
+// hx_h1_local_async: the row after a batch's lists -- element 0 = queries whose lists are not final, zeros after it
+__global__ void k_flag_row(const int* nfail, const int* spsum, uint64_t* row, int len) {
+  for (int i = threadIdx.x; i < len; i += blockDim.x)
+    row[i] = i == 0 ? (uint64_t)(uint32_t)(nfail[0] + spsum[0] + spsum[1]) : 0ull;
+}
+void launch_flag_row(const int* nfail, const int* spsum, uint64_t* row, int len, hipStream_t st) {
+  hipLaunchKernelGGL(k_flag_row, dim3(1), dim3(256), 0, st, nfail, spsum, row, len);
+  HX_HIP(hipGetLastError());
+}
+
 void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_fill<int>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);

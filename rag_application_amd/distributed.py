@@ -120,31 +120,83 @@ class ShardedIndex:
 
 class H1Pipeline:
     """Consecutive H1 batches in flight ("overlap the gather of batch i with K3 of batch
-    i+1 on a second stream").  `submit` runs the local stage of a batch on the current stream and hands
-    its exchange + fusion to a side stream, so they run beside the local stage of the next batch; the
-    returned tensors are valid once `wait()` (or a device synchronize) has passed.  With one rank, or
-    without a HIP device (the gloo tests), it degenerates to `ShardedIndex.hybrid_h1`."""
+    i+1 on a second stream").  `submit` enqueues the local stage of a batch on the current stream WITHOUT
+    reading its failure flags (`h1_local_async`) and hands its exchange + fusion to a side stream, so they
+    run beside the local stage of the next batch and the device never waits for the host.  The flags travel
+    through the exchange as one extra row per rank, so every rank sees every rank's word; a batch any rank
+    flagged (a retry or the exact path was needed: rare) is redone through the synchronous path, by all ranks
+    alike, when it is verified -- at the latest in `wait()`.  The returned tensors are valid once `wait()`
+    has passed.  With one rank, or without a HIP device (the gloo tests), there is no side stream and the
+    same steps run in sequence; without `h1_local_async` it degenerates to `ShardedIndex.hybrid_h1`."""
 
-    def __init__(self, sh: ShardedIndex, dense_limit=100, sparse_limit=100, limit=10, rrf_k=2.0, rank_base=0):
+    def __init__(self, sh: ShardedIndex, dense_limit=100, sparse_limit=100, limit=10, rrf_k=2.0, rank_base=0,
+                 depth: int = 2, force_side_stream: bool = False):
         self.sh = sh
         self.args = (dense_limit, sparse_limit, limit, rrf_k, rank_base)
         fast = hasattr(sh.local, "h1_local") and hasattr(sh.ops, "h1_fuse")
-        self.side = torch.cuda.Stream() if (sh.world > 1 and fast and torch.cuda.is_available()) else None
+        self.deferred = fast and hasattr(sh.local, "h1_local_async") and (sh.world > 1 or force_side_stream)
+        self.side = torch.cuda.Stream() if (self.deferred and torch.cuda.is_available()) else None
+        self.depth = max(1, depth)
+        self.pending = []          # batches whose flags have not been looked at yet, oldest first
+        self.redone = 0            # batches that went through the synchronous path after all
+        self._pin, self._n = None, 0   # ring of pinned host buffers for the ranks' flag words
+
+    def _exchange_and_fuse(self, mine, B):
+        sh = self.sh
+        dl, sl, limit, rrf_k, rank_base = self.args
+        g = mine if sh.world == 1 else sh.gather_raw(mine)              # [world * (B + 1), dl + sl], rank-major
+        g3 = g.view(sh.world, B + 1, dl + sl)
+        flags = g3[:, B, 0]
+        if flags.is_cuda:
+            if self._pin is None:
+                self._pin = [torch.empty((sh.world,), dtype=flags.dtype, pin_memory=True) for _ in range(self.depth + 2)]
+            host = self._pin[self._n % len(self._pin)]     # (more buffers than batches ever pending)
+            self._n += 1
+            host.copy_(flags, non_blocking=True)
+        else:
+            host = flags.clone()
+        out = sh.ops.h1_fuse(g3[:, :B, :].reshape(sh.world * B, dl + sl), sh.world, dl, sl, limit, rrf_k, rank_base)
+        return out, host
 
     def submit(self, q, q_indptr, q_idx, q_val):
         sh = self.sh
         dl, sl, limit, rrf_k, rank_base = self.args
-        if self.side is None:
+        if not self.deferred:
             return sh.hybrid_h1(q, q_indptr, q_idx, q_val, dl, sl, limit, rrf_k, rank_base)
-        mine = sh.local.h1_local(q, q_indptr, q_idx, q_val, dl, sl)   # returns once the stage's flags are read
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            out = sh.ops.h1_fuse(sh.gather_raw(mine), sh.world, dl, sl, limit, rrf_k, rank_base)
-        mine.record_stream(self.side)
+        B = q.shape[0]
+        mine = sh.local.h1_local_async(q, q_indptr, q_idx, q_val, dl, sl)      # enqueued; no host round trip
+        done = None
+        if self.side is not None:
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                out, host = self._exchange_and_fuse(mine, B)
+                done = torch.cuda.Event()
+                done.record()
+            mine.record_stream(self.side)
+        else:
+            out, host = self._exchange_and_fuse(mine, B)
+        self.pending.append((done, host, (q, q_indptr, q_idx, q_val), out))
+        while len(self.pending) > self.depth:
+            self._verify(self.pending.pop(0))
         return out
 
+    def _verify(self, entry):
+        done, host, inputs, out = entry
+        if done is not None:
+            done.synchronize()
+        if bool((host != 0).any()):        # the same words on every rank: all ranks redo the batch together
+            dl, sl, limit, rrf_k, rank_base = self.args
+            if self.side is not None:      # the lists being replaced must not be written by the side stream any more
+                torch.cuda.current_stream().wait_stream(self.side)
+            k, c = self.sh.hybrid_h1(*inputs, dl, sl, limit, rrf_k, rank_base)
+            out[0].copy_(k)
+            out[1].copy_(c)
+            self.redone += 1
+
     def wait(self):
+        while self.pending:
+            self._verify(self.pending.pop(0))
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)

@@ -219,6 +219,20 @@ class HxIndex:
                                      sparse_limit, _ptr(keys), _stream()))
         return keys
 
+    def h1_local_async(self, q: torch.Tensor, q_indptr: torch.Tensor, q_idx: torch.Tensor, q_val: torch.Tensor,
+                       dense_limit: int, sparse_limit: int) -> torch.Tensor:
+        """h1_local without the host round trip (hx_h1_local_async): [B + 1, dense_limit + sparse_limit]; row B,
+        element 0 = queries whose lists are not final (then the batch must be redone through h1_local)."""
+        q = _need_cuda(q, torch.float32, "q")
+        q_indptr = _need_cuda(q_indptr, torch.int64, "q_indptr")
+        q_idx = _need_cuda(q_idx, torch.int32, "q_idx")
+        q_val = _need_cuda(q_val, torch.float32, "q_val")
+        B = q.shape[0]
+        keys = torch.empty((B + 1, dense_limit + sparse_limit), dtype=torch.int64, device=q.device)
+        check(_lib.lib().hx_h1_local_async(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, dense_limit,
+                                           sparse_limit, _ptr(keys), _stream()))
+        return keys
+
     def rescore(self, q: torch.Tensor, cand_keys: torch.Tensor, cand_counts: Optional[torch.Tensor],
                 limit: int, prefix: int = 0):
         q = _need_cuda(q, torch.float32, "q")

@@ -88,6 +88,7 @@ def test_argument_errors_are_reported_not_crashed(lib_path):
         lambda: lib.hx_h1_fuse(0, p, 100, 1, 100, 100, 10, 2.0, 0, p, pc, None),      # world x limit > 8192
         lambda: lib.hx_h1_fuse(0, p, 2, 1, 4, 4, 0, 2.0, 0, p, pc, None),             # limit 0
         lambda: lib.hx_h1_local(None, p, p, p, p, 1, 4, 4, p, None),                  # NULL index
+        lambda: lib.hx_h1_local_async(None, p, p, p, p, 1, 4, 4, p, None),            # NULL index
         lambda: lib.hx_search_dense(None, p, 1, 0, 4, p, pc, None),
         lambda: lib.hx_save(None, b"/tmp/x.hx"),
     ]

@@ -105,6 +105,22 @@ class FakeShardH1(FakeShard):
                          dim=1)
 
 
+    # the call that does not read the flags: one more row, element 0 = the shard's flag word.  `bad_calls`: the
+    # calls (by number) on which this stand-in pretends a stage flagged queries -- and hands out garbage lists,
+    # as a shard whose lists are not final may
+    bad_calls = ()
+    n_async = 0
+
+    def h1_local_async(self, q, qip, qix, qv, dense_limit, sparse_limit):
+        keys = self.h1_local(q, qip, qix, qv, dense_limit, sparse_limit)
+        row = torch.zeros((1, keys.shape[1]), dtype=keys.dtype)
+        if self.n_async in self.bad_calls:
+            keys = torch.zeros_like(keys)
+            row[0, 0] = 3
+        self.n_async += 1
+        return torch.cat([keys, row], dim=0)
+
+
 class CpuOpsH1(CpuOps):
     @staticmethod
     def h1_fuse(gathered, world, dense_limit, sparse_limit, limit, k, rank_base):
@@ -142,11 +158,16 @@ def worker(rank, world, port, n, dim, B, ret):
     assert torch.equal(h2k, hk) and torch.equal(h2c, hc)
     # ... and through the batch pipeline (no side stream without a HIP device: it degenerates to the call above)
     from rag_application_amd.distributed import H1Pipeline
-    pipe = H1Pipeline(ShardedIndex(FakeShardH1(ora, r0), ops=CpuOpsH1), 40, 30, 10)
-    p1 = pipe.submit(Q, *tq)
-    p2 = pipe.submit(Q, *tq)
+    fake = FakeShardH1(ora, r0)
+    if rank == 1:
+        fake.bad_calls = (1,)              # ONE rank flags its second batch: every rank must redo that batch
+    pipe = H1Pipeline(ShardedIndex(fake, ops=CpuOpsH1), 40, 30, 10)
+    assert pipe.deferred and pipe.side is None
+    ps = [pipe.submit(Q, *tq) for _ in range(4)]
     pipe.wait()
-    assert torch.equal(p1[0], hk) and torch.equal(p2[0], hk) and torch.equal(p2[1], hc)
+    assert pipe.redone == 1 and not pipe.pending
+    for pk, pc in ps:
+        assert torch.equal(pk, hk) and torch.equal(pc, hc)
     ret[rank] = (tk.numpy(), tc.numpy(), hk.numpy(), hc.numpy(), dk.numpy(), dc.numpy())
     dist.barrier()
     dist.destroy_process_group()

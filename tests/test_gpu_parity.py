@@ -287,6 +287,21 @@ def test_h1_fusion_redone_after_a_dense_retry(eng, torch_mod, synth_tables):
         es, ei = O.hybrid_h1(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], 60, 50, 10)
         assert_list_equal(s1[b], i1[b], c1[b], es, ei, f"h1 after retry b={b}")
         assert_list_equal(s2[b], i2[b], c2[b], es, ei, f"h1_local/h1_fuse after retry b={b}")
+    # the same batch through the call that does NOT read the flags: its extra row says that lists are not final,
+    # and the pipeline that defers the check redoes the batch through the synchronous path
+    from rag_application_amd.distributed import ShardedIndex, H1Pipeline
+    a = ix.h1_local_async(Qd, *tq, 60, 50)
+    assert tuple(a.shape) == (B + 1, 110) and int(a[B, 0]) > 0 and int(a[B, 1:].abs().sum()) == 0
+    pipe = H1Pipeline(ShardedIndex(ix), 60, 50, 10, force_side_stream=True)
+    assert pipe.deferred and pipe.side is not None
+    outs = [pipe.submit(Qd, *tq) for _ in range(3)]
+    pipe.wait()
+    assert pipe.redone == 3
+    for k3, c3 in outs:
+        s3, i3, c3 = unpack_np(eng, k3, c3)
+        for b in range(B):
+            es, ei = O.hybrid_h1(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], 60, 50, 10)
+            assert_list_equal(s3[b], i3[b], c3[b], es, ei, f"deferred pipeline after retry b={b}")
     ix.close()
 
 
@@ -466,9 +481,11 @@ def test_h1_pipeline_batches_in_flight(eng, torch_mod, synth_tables):
     sh = ShardedIndex(shards[0])
     sh.world = 2
     cur = {}
-    sh.gather_raw = lambda mine: torch_mod.cat([mine, shards[1].h1_local(*cur["q"], 60, 50)], dim=0)
+    # (the pipeline's local stage is h1_local_async: B + 1 rows per rank, the last one the rank's flag word)
+    sh.gather_raw = lambda mine: torch_mod.cat(
+        [mine, (shards[1].h1_local_async if mine.shape[0] == B + 1 else shards[1].h1_local)(*cur["q"], 60, 50)], dim=0)
     pipe = H1Pipeline(sh, 60, 50, 10)
-    assert pipe.side is not None
+    assert pipe.side is not None and pipe.deferred
     batches, outs = [], []
     for t in range(nb):
         Q = torch_mod.from_numpy(O.synth_dense(O.SEED_QUERY, 1000 * t, B, dim)).cuda()
@@ -480,6 +497,7 @@ def test_h1_pipeline_batches_in_flight(eng, torch_mod, synth_tables):
         cur["q"] = batches[t]
         outs.append(pipe.submit(*batches[t]))
     pipe.wait()
+    assert pipe.redone == 0 and not pipe.pending
     hp = eng.make_params(dict(matryoshka_64_limit=1, matryoshka_128_limit=1, matryoshka_256_limit=1, dense_limit=60,
                               quantized_limit=1, sparse_limit=50, final_limit=10, hnsw_ef=1), mode=eng.HX_MODE_H1)
     for t in range(nb):
