@@ -300,6 +300,9 @@ def main():
 
     empty_sp = (torch.zeros(B + 1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
                 torch.zeros(0, dtype=torch.float32, device=dev))
+    # the three header words of a batch travel over a host-side group: over RCCL reading them would park the host
+    # behind the previous batch's kernels and the device would idle while it catches up (sharded.bcast_queries)
+    hdr_group = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
 
     def step():
         if world == 1:
@@ -307,7 +310,7 @@ def main():
                 return ix.hybrid_query(Q, qip_d, qix_d, qv_d, hp)    # whole pipeline behind one ABI call
             return sh.search_dense(Q, 10)
         q, ip, ixx, vv = bcast_queries(Q, *((qip_d, qix_d, qv_d) if mode == "h1" else (empty_sp if rank == 0 else (None,) * 3)),
-                                       src=0, device=dev)
+                                       src=0, device=dev, header_group=hdr_group)
         if mode == "h1":
             if pipe is not None:
                 return pipe.submit(q, ip, ixx, vv)
@@ -316,6 +319,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.wait()
     ix.profile(True)
     ix.profile_read()
     if world > 1:
@@ -324,6 +329,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    if pipe is not None:
+        pipe.wait()          # every batch's flag words looked at (a flagged batch is redone here at the latest)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -40,9 +40,14 @@ def _dev_of(group) -> torch.device:
     return torch.device("cpu")
 
 
-def bcast_queries(q, q_indptr, q_idx, q_val, src: int = 0, group=None, device: Optional[torch.device] = None):
+def bcast_queries(q, q_indptr, q_idx, q_val, src: int = 0, group=None, device: Optional[torch.device] = None,
+                  header_group=None):
     """C2: the query batch from `src` to every rank.  A 3-word header (B, D, nnz), then ONE broadcast of a packed
-    byte buffer [indptr int64 | Q float32 | idx int32 | val float32].  Returns the four tensors on every rank."""
+    byte buffer [indptr int64 | Q float32 | idx int32 | val float32].  Returns the four tensors on every rank.
+    `header_group`: a host-side (gloo) group with the same ranks for the header.  Over RCCL the header broadcast is
+    queued behind everything the device still has to do, and reading its three words would park the host until
+    the previous batch's kernels are through -- with a stream of batches in flight (distributed.H1Pipeline) the
+    device would then idle while the host catches up.  Over the host group only the payload touches the device."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = device or _dev_of(group)
@@ -51,14 +56,15 @@ def bcast_queries(q, q_indptr, q_idx, q_val, src: int = 0, group=None, device: O
                 torch.as_tensor(q_idx, dtype=torch.int32, device=dev), torch.as_tensor(q_val, dtype=torch.float32, device=dev))
     # the collective runs where the backend works: on the device for RCCL, on the host for gloo (CPU tests, rehearsals)
     cdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    head = torch.zeros(3, dtype=torch.int64, device=cdev)
+    hdev = torch.device("cpu") if header_group is not None else cdev
+    head = torch.zeros(3, dtype=torch.int64, device=hdev)
     if rank == src:
         q = torch.as_tensor(q, dtype=torch.float32).contiguous()
         q_indptr = torch.as_tensor(q_indptr, dtype=torch.int64).contiguous()
         q_idx = torch.as_tensor(q_idx, dtype=torch.int32).contiguous()
         q_val = torch.as_tensor(q_val, dtype=torch.float32).contiguous()
-        head = torch.tensor([q.shape[0], q.shape[1], q_idx.shape[0]], dtype=torch.int64, device=cdev)
-    dist.broadcast(head, src, group=group)
+        head = torch.tensor([q.shape[0], q.shape[1], q_idx.shape[0]], dtype=torch.int64, device=hdev)
+    dist.broadcast(head, src, group=header_group if header_group is not None else group)
     B, D, nnz = (int(x) for x in head.tolist())
     sizes = [(B + 1) * 8, B * D * 4, nnz * 4, nnz * 4]
     buf = torch.empty(sum(sizes), dtype=torch.uint8, device=cdev)

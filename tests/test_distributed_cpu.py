@@ -227,6 +227,10 @@ def front_worker(rank, world, port, n, dim, B, ret):
     Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
     qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, tabs)
     got = bcast_queries(*((Q, qip, qsi.astype(np.int32), qsv) if rank == 0 else (None,) * 4))
+    # ... and with the header on a host-side group of its own (what bench.py does beside RCCL)
+    got2 = bcast_queries(*((Q, qip, qsi.astype(np.int32), qsv) if rank == 0 else (None,) * 4),
+                         header_group=dist.new_group(backend="gloo"))
+    assert all(torch.equal(a, b) for a, b in zip(got, got2))
     assert np.array_equal(got[0].numpy(), Q) and np.array_equal(got[1].numpy(), qip)
     assert np.array_equal(got[2].numpy(), qsi.astype(np.int32)) and np.array_equal(got[3].numpy(), qsv)
     # -- the handler: rank 0 is the application, the others serve
