@@ -462,6 +462,34 @@ def test_two_shards_one_gpu_merge_equals_unsharded(eng, torch_mod, synth_tables)
         s.close()
 
 
+def test_h1_local_async_edge_cases(eng, torch_mod, synth_tables):
+    """hx_h1_local_async: the rows of the batch equal hx_h1_local's, the extra row is the flag word (0 when no stage
+    flagged a query); an EMPTY shard and a shard without sparse vectors enqueue fewer stages and still say 0."""
+    dim, B = 64, 37
+    Q = torch_mod.from_numpy(O.synth_dense(O.SEED_QUERY, 0, B, dim)).cuda()
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
+    empty = eng.HxIndex(dim, ())
+    a = empty.h1_local_async(Q, *tq, 20, 10)
+    assert tuple(a.shape) == (B + 1, 30) and int(a.abs().sum()) == 0
+    empty.close()
+    n = 5000
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    for with_sparse in (True, False):
+        ix = eng.HxIndex(dim, ())
+        if with_sparse:
+            ix.add(X, ip, si.astype(np.int32), sv)
+        else:
+            ix.add(X)
+        a = ix.h1_local_async(Q, *tq, 20, 10)
+        b = ix.h1_local(Q, *tq, 20, 10)
+        assert torch_mod.equal(a[:B], b) and int(a[B].abs().sum()) == 0, f"with_sparse={with_sparse}"
+        if not with_sparse:
+            assert int(a[:B, 20:].abs().sum()) == 0          # no sparse lists
+        ix.close()
+
+
 def test_h1_pipeline_batches_in_flight(eng, torch_mod, synth_tables):
     """distributed.H1Pipeline: several batches submitted back to back, their exchange + fusion on the
     side stream while the next local stage runs.  Two shards on one GPU; the "all-gather" of shard 0 is
