@@ -17,23 +17,25 @@
 // within M units of the L-th.
 //
 // Index layout (spbuild.hip): TERM-major postings sorted by (term, document) as {place of the document's
-// accumulator inside its segment (sp_word below), fp32 weight}; documents are cut into segments of SEG_DOCS and a dense table gives, for
-// every live term and segment, the offset of the term's first posting in that segment or later.
+// accumulator inside its segment (sp_word below), fp32 weight}; documents are cut into segments of SEG_DOCS
+// and a dense table gives, for every live term and segment, the offset of the term's first posting in that
+// segment or later.
 //
 // One workgroup owns (query, part): a contiguous range of segments and an LDS accumulator of one 16-bit
 // half-word per document of a segment (document d: word d mod SEG_DOCS/2, half d div SEG_DOCS/2, so the
 // neighbours of a posting run never share a word).  Lane t of every wave holds query term t (T <= 64):
 // its table row and the run [p0, p1) of the current segment.  A run is cut into chunks of 128 postings
 // (two per lane); every wave derives the same chunk list from a wave-wide DPP scan of the chunk counts
-// and wave w takes chunks w, w + W, ...: the first SP_K of them are loaded one visit AHEAD into
+// and wave w takes chunks w, w + W, ...: the first SP_K of them are loaded two visits AHEAD into
 // registers, the rest (unusually dense segments) straight from memory.
-//     visit(s):  derive the chunks of s + 1, issue their posting loads and the table offsets of s + 3
+//     visit(s):  derive the chunks of s + 2, issue their posting loads; read the table offsets of s + 3
 //                accumulate(s): ds_add_u32 of v << (16 * half)              -- barrier X --
 //                harvest(s): ds_and_rtn_b32 clears the half and returns the word: the lane that gets a
 //                non-zero half back owns the document; a >= tau appends a key     -- barrier Y --
 // Both barriers wait for LDS only, so the loads of the next visit stay in flight across them.
-// Survivors go to a workgroup-private buffer in global memory that is sorted through the (then all-zero)
-// accumulator and cut to {a > a_L - M} whenever it has grown enough; tau follows.
+// Survivors go to a workgroup-private buffer in global memory that is cut to {a > a_L - M} whenever it has
+// grown enough -- a histogram of the 16-bit scores over the (then all-zero) accumulator finds a_L, nothing is
+// sorted before the last cut (sp_cut); tau follows.
 #include "hx_common.hpp"
 #include "kernels.hpp"
 #include "wsort.hpp"
@@ -60,7 +62,7 @@ constexpr int SEG_DOCS = HX_SEG_DOCS;
 constexpr int SEG_WORDS = SEG_DOCS / 2;      // accumulator words (two documents each)
 constexpr int SEG_WSHIFT = SEG_DOCS == 65536 ? 15 : 14;
 static_assert((1 << SEG_WSHIFT) == SEG_WORDS, "segment size");
-constexpr int SP_CAP = SEG_DOCS / 4;         // candidate keys the LDS can sort (the accumulator as scratch)
+constexpr int SP_CAP = SEG_DOCS / 4;         // candidate keys the LDS can stage at a cut (the accumulator as scratch)
 constexpr int SP_GCAP = SEG_DOCS + SP_CAP / 2;   // keys of the workgroup's buffer in global memory: a visit appends
                                              // at most one key per document of the segment
 constexpr int SP_HSHIFT = SEG_DOCS == 65536 ? 1 : 2;   // histogram pre-filter: SEG_WORDS 32-bit bins of 2 / 4 scores
@@ -91,7 +93,7 @@ __device__ unsigned long long g_sp_stamps[2 * 8 * 4096];
 struct SpShared {
   union {
     uint32_t acc[SEG_WORDS];                 // two 16-bit integer scores per word
-    uint64_t sort[SP_CAP];                   // sort scratch while acc is all zero
+    uint64_t sort[SP_CAP];                   // the kept keys of a cut (sorted at the last one) while acc is all zero
   };
   int cnt;                                   // candidates in the workgroup's global buffer
   int ovf;                                   // an append found the buffer full
