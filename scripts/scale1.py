@@ -1,3 +1,4 @@
+"""Diagnostic: stage-by-stage timing of one index (reserve / fill / finalize / each search stage).  argv: rows batch [dim]"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import oracle as O
