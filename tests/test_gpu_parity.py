@@ -462,6 +462,40 @@ def test_two_shards_one_gpu_merge_equals_unsharded(eng, torch_mod, synth_tables)
         s.close()
 
 
+def test_large_batches_go_through_in_slices(eng, torch_mod, synth_tables):
+    """hx_hybrid_query_dev with B = 4300 (tree and H1): the engine slices batches beyond 4096 (engine.hip: hybrid_query_dev);
+    every row equals the same query asked in a small batch of its own, and a sample equals the oracle."""
+    n, dim, B = 20000, 64, 4300
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    ora = O.OracleIndex(dim, (64,))
+    ora.add(X, ip, si, sv)
+    ora.finalize()
+    ix = eng.HxIndex(dim, (64,))
+    ix.add(X, ip, si.astype(np.int32), sv)
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
+    P = dict(matryoshka_64_limit=30, matryoshka_128_limit=1, matryoshka_256_limit=1, dense_limit=25, quantized_limit=20,
+             sparse_limit=20, final_limit=10, hnsw_ef=1)
+    for mode in (eng.HX_MODE_H1, eng.HX_MODE_TREE):
+        hp = eng.make_params(P, mode=mode)
+        k, c = ix.hybrid_query(Qd, *tq, hp)
+        for b0, b1 in ((0, 700), (1400, 1500), (2100, 2200), (4096, 4300)):   # the same queries in batches of their own
+            ipb = tq[0][b0:b1 + 1] - tq[0][b0]
+            lo, hi = int(tq[0][b0]), int(tq[0][b1])
+            k2, c2 = ix.hybrid_query(Qd[b0:b1].contiguous(), ipb.contiguous(), tq[1][lo:hi].contiguous(),
+                                     tq[2][lo:hi].contiguous(), hp)
+            assert torch_mod.equal(k[b0:b1], k2) and torch_mod.equal(c[b0:b1], c2), f"mode {mode} rows {b0}:{b1}"
+        s, i, cc = unpack_np(eng, k, c)
+        for b in (0, 2149, 2150, 4299):
+            sp = (qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]])
+            es, ei = (O.hybrid_h1(ora, Q[b], *sp, 25, 20, 10) if mode == eng.HX_MODE_H1 else O.hybrid_tree(ora, Q[b], *sp, P))
+            assert_list_equal(s[b], i[b], cc[b], es, ei, f"mode {mode} b={b}")
+    ix.close()
+
+
 def test_h1_local_async_edge_cases(eng, torch_mod, synth_tables):
     """hx_h1_local_async: the rows of the batch equal hx_h1_local's, the extra row is the flag word (0 when no stage
     flagged a query); an EMPTY shard and a shard without sparse vectors enqueue fewer stages and still say 0."""
