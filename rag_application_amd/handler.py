@@ -126,7 +126,7 @@ class QdrantHandler:
                 raise ValueError("user_id cannot be empty")
             user_id = str(user_id)
             if user_id in self._collections and not force_recreate:
-                logging.info(f"Collection for user {user_id} already exists, skipping creation")
+                logging.info("create_collection: %s is already there", user_id)
                 return
             if quantized_size != dense_vector_size:
                 raise ValueError("quantized_size must equal dense_vector_size")
@@ -146,9 +146,9 @@ class QdrantHandler:
                     col.sparse_enabled = bool(sparse_enabled)
                 self._collections[user_id] = col
             await self._run(make)
-            logging.info(f"Created hybrid search collection for user {user_id}")
+            logging.info("create_collection: new collection for %s", user_id)
         except ValueError as ve:
-            logging.error(f"Validation error creating collection for user {user_id}: {str(ve)}")
+            logging.error("create_collection(%s) refused: %s", user_id, ve)
             raise
         except Exception as e:
             logging.critical(f"Collection creation failed for user {user_id}: {str(e)}")
@@ -223,9 +223,9 @@ class QdrantHandler:
                     "category": metadata.get("category"),
                 }
             n = await self._store(user_id, embedded_chunks, payload)
-            logging.info(f"Stored {n} chunks with multi-stage embeddings for user {user_id}")
+            logging.info("store_document_vectors: %d chunks added for %s", n, user_id)
         except Exception as e:
-            logging.error(f"Failed to store vectors: {str(e)}")
+            logging.error("store_document_vectors failed: %s", e)
             raise
 
     async def store_chat_vectors(self, embedded_payload: List[Dict[str, Any]], user_id: str):
@@ -245,9 +245,9 @@ class QdrantHandler:
                     "is_chat": True,
                 }
             n = await self._store(user_id, embedded_payload, payload)
-            logging.info(f"Stored {n} chat messages with embeddings for user {user_id}")
+            logging.info("store_chat_vectors: %d messages added for %s", n, user_id)
         except Exception as e:
-            logging.error(f"Failed to store chat vectors: {str(e)}")
+            logging.error("store_chat_vectors failed: %s", e)
             raise
 
     # ---------------------------------------------------------------------------- search
@@ -296,7 +296,7 @@ class QdrantHandler:
             reranked_results = await self.rerank_with_colbert(query_text, documents, results, max_tokens_per_doc)
             return reranked_results[:top_k]
         except Exception as e:
-            logging.error(f"Hybrid search failed for user {user_id}: {str(e)}")
+            logging.error("hybrid search for %s failed: %s", user_id, e)
             return []
 
     async def hybrid_search_batch(self, user_id: str, dense_vectors, sparse_vectors, top_k: int = 10,
@@ -307,7 +307,7 @@ class QdrantHandler:
             res = await self._run(self._search_sync, user_id, dense_vectors, sparse_vectors, search_params, filters)
             return [r[:top_k] for r in res]
         except Exception as e:
-            logging.error(f"Hybrid search failed for user {user_id}: {str(e)}")
+            logging.error("hybrid search for %s failed: %s", user_id, e)
             return []
 
     async def rerank_with_colbert(self, query: str, documents: List[str], results: List[Dict],
@@ -320,7 +320,7 @@ class QdrantHandler:
                 return results
             return [results[i] for i in ranked_indices]
         except Exception as e:
-            logging.error(f"Reranking failed: {str(e)}")
+            logging.error("reranker raised, order kept: %s", e)
             return results
 
     # ------------------------------------------------------------------------ collections
@@ -328,7 +328,7 @@ class QdrantHandler:
         try:
             return list(self._collections.keys())
         except Exception as e:
-            logging.error(f"Failed to fetch user collections: {str(e)}")
+            logging.error("get_all_containers failed: %s", e)
             return []
 
     async def delete_collection(self, user_id: str):
@@ -337,15 +337,15 @@ class QdrantHandler:
                 col = self._collections.pop(str(user_id))   # KeyError if absent: re-raised
                 col.close()
             await self._run(drop)
-            logging.info(f"Deleted collection for user {user_id}")
+            logging.info("delete_collection: %s dropped", user_id)
         except Exception as e:
-            logging.error(f"Failed to delete collection for user {user_id}: {str(e)}")
+            logging.error("delete_collection(%s) failed: %s", user_id, e)
             raise
 
     async def get_collection_chunk_count(self, user_id: str, filters: Optional[Dict] = None) -> int:
         try:
             if str(user_id) not in self._collections:
-                logging.warning(f"Collection for user {user_id} does not exist.")
+                logging.warning("get_collection_chunk_count: no collection for %s", user_id)
                 return 0
             col = self._collections[str(user_id)]
             if filters:   # :464-470: count the points the filter keeps
@@ -353,5 +353,5 @@ class QdrantHandler:
                                                    if _filters.matches(p, filters, i)))
             return await self._run(col.index.count)
         except Exception as e:
-            logging.error(f"Failed to get chunk count for user {user_id}: {str(e)}")
+            logging.error("get_collection_chunk_count(%s) failed: %s", user_id, e)
             return 0

@@ -340,7 +340,7 @@ class ShardedHandler:
                                                 "document_summary": md.get("doc_summary"),
                                                 "file_description": md.get("description")})
         except Exception as e:
-            logging.error(f"Failed to store vectors: {str(e)}")
+            logging.error("store_document_vectors failed: %s", e)
             raise                                                           # :196-198
 
     async def hybrid_search_batch(self, user_id: str, dense_vectors, sparse_vectors, top_k: int = 10,
@@ -368,7 +368,7 @@ class ShardedHandler:
                             for s, sc in row][:top_k])
             return out
         except Exception as e:
-            logging.error(f"Hybrid search failed: {str(e)}")
+            logging.error("hybrid search failed: %s", e)
             return [[] for _ in sparse_vectors] if sparse_vectors is not None else []     # :384-386
 
     async def hybrid_search(self, user_id: str, query_text: str, dense_vector, sparse_vector, image_embedding=None,
