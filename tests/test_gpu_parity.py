@@ -565,6 +565,28 @@ def test_h1_pipeline_batches_in_flight(eng, torch_mod, synth_tables):
     for t in range(nb):
         k1, c1 = one.hybrid_query(*batches[t], hp)
         assert torch_mod.equal(outs[t][1], c1) and torch_mod.equal(outs[t][0], k1), f"batch {t}"
+    # the OTHER shard flags one batch (and hands out garbage lists for it, as a shard whose lists are not final
+    # may): this rank learns it from the gathered rows two submits later and redoes that batch -- and only that one
+    calls = {"n": 0}
+
+    def gather_flagging(mine):
+        if mine.shape[0] != B + 1:                       # the synchronous redo
+            return torch_mod.cat([mine, shards[1].h1_local(*batches[0], 60, 50)], dim=0)
+        other = shards[1].h1_local_async(*batches[0], 60, 50)
+        if calls["n"] == 1:
+            other = torch_mod.zeros_like(other)
+            other[B, 0] = 2
+        calls["n"] += 1
+        return torch_mod.cat([mine, other], dim=0)
+
+    sh.gather_raw = gather_flagging
+    pipe2 = H1Pipeline(sh, 60, 50, 10)
+    outs2 = [pipe2.submit(*batches[0]) for _ in range(4)]
+    pipe2.wait()
+    assert pipe2.redone == 1
+    k1, c1 = one.hybrid_query(*batches[0], hp)
+    for t, (k2, c2) in enumerate(outs2):
+        assert torch_mod.equal(k2, k1) and torch_mod.equal(c2, c1), f"flagged run, batch {t}"
     for s in shards + [one]:
         s.close()
 
