@@ -19,8 +19,9 @@
  *     `keys[b*stride + r]`, r = rank, sorted best-first, with `counts[b]` valid
  *     entries; key = (orderable(score) << 32) | (0xFFFFFFFF - id), so that the
  *     descending integer order IS the engine's total order (score descending,
- *     id ascending).  0 marks an empty slot.  ids are global row ids
- *     (id_base + local row), < 2^32 - 1.
+ *     id ascending).  0 marks an empty slot.  ids are global row ids, < 2^32 - 1:
+ *     id_base + local row, or -- a shard that holds slices of many batches -- the
+ *     insertion-order ids named batch by batch with hx_set_next_id.
  *   - no torch types, no C++ types: plain pointers and sizes only.
  */
 #ifndef HX_H
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HX_ABI_VERSION 1
+#define HX_ABI_VERSION 2   /* 2: hx_set_next_id, hx_add_rows_dev, hx_truncate; max_terms dropped from two entries */
 
 typedef struct hx_index hx_index;
 
@@ -100,6 +101,20 @@ int hx_add_sparse(hx_index* h, const int64_t* indptr_host, const int32_t* idx_ho
  * sparse vectors.  A failure leaves the index exactly as it was. */
 int hx_add_rows(hx_index* h, const float* rows_host, const int64_t* indptr_host, const int32_t* idx_host,
                 const float* val_host, int64_t n);
+/* hx_add_rows for dense rows that already lie on the device (the output of an encoder on PyTorch-ROCm): the same
+ * all-or-nothing contract, the sparse CSR still comes from the host (bm25 runs on the host cores). */
+int hx_add_rows_dev(hx_index* h, const float* rows_dev, const int64_t* indptr_host, const int32_t* idx_host,
+                    const float* val_host, int64_t n, void* stream);
+/* Row sharding with insertion-order ids (the reference upserts a collection in MANY batches,
+ * app/services/file_processor/text_processor.py:357 -> qdrant_handler.py:190-193; a shard then holds a slice of
+ * every batch): the NEXT add call's rows get the global ids first_id, first_id + 1, ...  Ids must ascend with the
+ * rows of a shard (first_id >= every id given so far).  Without this call a batch continues the ids of the previous
+ * one, starting at hx_create's id_base.  Every key that leaves the index carries global ids, and hx_rescore takes
+ * global ids; a failed add consumes the call. */
+int hx_set_next_id(hx_index* h, int64_t first_id);
+/* Roll the collection back to its first n_rows rows (dense and sparse): how the shards that stored their slice of
+ * a batch undo it when another shard could not (one upsert = one request in the reference, :190-193). */
+int hx_truncate(hx_index* h, int64_t n_rows);
 /* build the on-device inverted index over everything added so far; searches
  * call it implicitly when the index is stale. */
 int hx_finalize(hx_index* h);
@@ -131,10 +146,11 @@ int hx_search_dense(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, 
 int hx_search_i8(hx_index* h, const float* q_dev, int32_t B, int32_t limit,
                  uint64_t* keys_dev, int32_t* counts_dev, void* stream);
 /* Prefetch(query=SparseVector, using="sparse", limit) (qdrant_handler.py:347-354).
- * Query batch as CSR on the device: indptr[B+1] (int64), idx (int32, ascending and
- * unique within a query), val (fp32). */
+ * Query batch as CSR on the device: indptr[B+1] (int64), idx (int32, strictly ascending
+ * within a query: the exact score is a running fp32 sum in that order; the device checks it
+ * and the call fails for a query that is not), val (fp32, finite). */
 int hx_search_sparse(hx_index* h, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
-                     const float* q_val_dev, int32_t B, int32_t max_terms, int32_t limit,
+                     const float* q_val_dev, int32_t B, int32_t limit,
                      uint64_t* keys_dev, int32_t* counts_dev, void* stream);
 
 /* ---- candidate stages ------------------------------------------------------ */
@@ -194,10 +210,10 @@ int hx_hybrid_query_host(hx_index* h, const float* q_dense_host,
                          const int64_t* q_indptr_host, const int32_t* q_idx_host,
                          const float* q_val_host, int32_t B, const hx_params* p,
                          float* scores_host, int64_t* ids_host, int32_t* counts_host);
-/* same, device-resident inputs and outputs (bench path; sparse idx sorted) */
+/* same, device-resident inputs and outputs (bench path; sparse idx strictly ascending per query, checked) */
 int hx_hybrid_query_dev(hx_index* h, const float* q_dense_dev,
                         const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
-                        const float* q_val_dev, int32_t B, int32_t max_terms, const hx_params* p,
+                        const float* q_val_dev, int32_t B, const hx_params* p,
                         uint64_t* keys_dev, int32_t* counts_dev, void* stream);
 
 /* ---- sparse text provider (host cores) ---------------------------------------

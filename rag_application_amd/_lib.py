@@ -55,6 +55,9 @@ _SIGS = {
     "hx_add_dense_dev": [_P, _P, C.c_int64, _P],
     "hx_add_sparse": [_P, _P, _P, _P, C.c_int64],
     "hx_add_rows": [_P, _P, _P, _P, _P, C.c_int64],
+    "hx_add_rows_dev": [_P, _P, _P, _P, _P, C.c_int64, _P],
+    "hx_set_next_id": [_P, C.c_int64],
+    "hx_truncate": [_P, C.c_int64],
     "hx_finalize": [_P],
     "hx_count": [_P, C.POINTER(C.c_int64)],
     "hx_nnz": [_P, C.POINTER(C.c_int64)],
@@ -62,7 +65,7 @@ _SIGS = {
     "hx_synth_queries_dense": [C.c_int32, C.c_int64, C.c_int32, C.c_uint32, _P, _P],
     "hx_search_dense": [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P],
     "hx_search_i8": [_P, _P, C.c_int32, C.c_int32, _P, _P, _P],
-    "hx_search_sparse": [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P],
+    "hx_search_sparse": [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P],
     "hx_rescore": [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, _P],
     "hx_rrf": [C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_float, C.c_int32,
                C.c_int32, _P, _P, _P],
@@ -73,7 +76,7 @@ _SIGS = {
                    _P, _P, _P],
     "hx_unpack": [C.c_int32, _P, C.c_int64, _P, _P, _P],
     "hx_hybrid_query_host": [_P, _P, _P, _P, _P, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
-    "hx_hybrid_query_dev": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
+    "hx_hybrid_query_dev": [_P, _P, _P, _P, _P, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
     "hx_bm25_embed_batch": [_P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int32, _P, _P, _P, C.c_int64, _P],
     "hx_save": [_P, C.c_char_p],
     "hx_load": [C.c_char_p, C.c_int32, C.POINTER(_P)],
@@ -106,7 +109,7 @@ def lib() -> C.CDLL:
             f.restype = C.c_int
         l.hx_last_error.argtypes = []
         l.hx_last_error.restype = C.c_char_p
-        if l.hx_abi_version() != 1:
+        if l.hx_abi_version() != 2:
             raise HxError("libhx ABI version mismatch")
         _lib = l
     return _lib

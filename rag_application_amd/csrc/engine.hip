@@ -15,6 +15,7 @@
 #include <limits>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <cmath>
 #include <numeric>
@@ -46,6 +47,42 @@ struct Workspace {
   }
 };
 
+// Scratch of the index-free entries (hx_rrf, hx_merge, hx_h1_fuse): one Workspace per (device, calling thread), so
+// two threads fusing lists on one device never share buffers.  A thread that exits hands its workspaces to a pool
+// the next new thread takes them from: executor threads come and go, the device memory they used does not pile up
+// -- and nothing calls hipFree from a thread-exit (or process-exit) destructor, where the runtime may be gone.
+struct WorkspacePool {
+  std::mutex mu;
+  std::map<int, std::vector<Workspace*>> idle;   // device -> workspaces without a thread
+  Workspace* take(int device) {
+    std::lock_guard<std::mutex> g(mu);
+    auto& v = idle[device];
+    if (v.empty()) return new Workspace();
+    Workspace* w = v.back();
+    v.pop_back();
+    return w;
+  }
+  void give(int device, Workspace* w) {
+    std::lock_guard<std::mutex> g(mu);
+    idle[device].push_back(w);
+  }
+};
+static WorkspacePool& ws_pool() {
+  static WorkspacePool* p = new WorkspacePool();   // never destroyed: threads may exit after main returns
+  return *p;
+}
+struct ThreadWorkspaces {
+  std::map<int, Workspace*> by_device;
+  Workspace& get(int device) {
+    auto it = by_device.find(device);
+    if (it == by_device.end()) it = by_device.emplace(device, ws_pool().take(device)).first;
+    return *it->second;
+  }
+  ~ThreadWorkspaces() {
+    for (auto& kv : by_device) ws_pool().give(kv.first, kv.second);
+  }
+};
+
 enum WsSlot {
   WS_QN = 1, WS_QH, WS_Q8, WS_RINVQ, WS_CAND, WS_CAND2, WS_CNT, WS_CNT2, WS_OVF, WS_TAU, WS_FAIL,
   WS_NFAIL, WS_QSEL, WS_FB_KEYS, WS_FB_CNT, WS_FB_INCNT, WS_SP_PARTS, WS_SP_PCNT, WS_RAW, WS_RS_TMP,
@@ -54,7 +91,8 @@ enum WsSlot {
   WS_H_SC, WS_H_ID, WS_SYN_NNZ, WS_RRF_TMP, WS_MISC, WS_SP_CAND, WS_SP_PARK, WS_SP_ORDER, WS_HITLOG, WS_HITCNT, WS_KEPT,
   WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC,
   WS_SP_TI0, WS_SP_TI1, WS_SP_QS, WS_SP_MARGIN, WS_SP_FLAG, WS_SP_WORK, WS_SP_FAIL, WS_SP_LIST, WS_SP_LCNT,
-  WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF, WS_SP_QPARTS, WS_SP_SUM
+  WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF, WS_SP_QPARTS, WS_SP_SUM,
+  WS_ID_IN, WS_LONG_ROWS
 };
 
 template <typename T>
@@ -123,6 +161,21 @@ struct hx_index {
   bool sp_sum_pending = false;        // a sparse_enqueue's summary has not been consumed by sparse_resolve yet
   bool sp_sum_fetched = false;        // ... and is already in sp_sum (a dense stage's flag read took it along)
   int sp_sum[2] = {0, 0};             // flagged-or-failed queries, any invalid query
+
+  // Insertion-order ids under row sharding.  Inside the engine a row's id is id_base + local
+  // row.  What crosses the ABI is the row's GLOBAL id: rows arrive in blocks, block k = local rows
+  // [row0[k], row0[k + 1]) with global ids gid0[k], gid0[k] + 1, ... (hx_set_next_id names the first id of the next
+  // block; without it a block continues the previous one).  Both columns ascend, so the map is monotone: the order
+  // (score desc, id asc) of a list is the same in both id spaces, and the remap is one pass over the keys a stage
+  // hands out (and over the candidate keys hx_rescore takes in).  One block starting at id_base = the identity.
+  struct IdBlocks {
+    std::vector<uint32_t> row0, gid0;
+    uint32_t* dev = nullptr;          // row0[0, nb) then gid0[0, nb)
+    int dev_cap = 0;
+    bool dirty = false;
+    int64_t next = -1;                // hx_set_next_id: global id of the next appended row (-1: continue)
+    int64_t end = -1;                 // global id after the last row (-1: no row yet)
+  } ids;
 
   void set_device() const { HX_HIP(hipSetDevice(device)); }
 };
@@ -256,6 +309,74 @@ static void finalize(hx_index* h, hipStream_t st) {
   }
   h->sparse_stale = false;
 }
+
+// ---------------------------------------------------------------------------------
+// global (insertion-order) ids: hx_index::IdBlocks
+// ---------------------------------------------------------------------------------
+static bool ids_identity(const hx_index* h) {
+  const auto& b = h->ids;
+  return b.row0.empty() || (b.row0.size() == 1 && (int64_t)b.gid0[0] == h->id_base);
+}
+// first global id the next n rows would get; refuses before anything is stored
+static int64_t ids_next(const hx_index* h, int64_t n) {
+  const auto& b = h->ids;
+  const int64_t cont = b.end >= 0 ? b.end : h->id_base;
+  const int64_t g = b.next >= 0 ? b.next : cont;
+  HX_CHECK(g >= cont, "hx_set_next_id: the ids of a shard must ascend with its rows");
+  HX_CHECK(g + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
+  return g;
+}
+static void ids_commit(hx_index* h, int64_t row_first, int64_t n) {
+  auto& b = h->ids;
+  if (n <= 0) return;
+  const int64_t cont = b.end >= 0 ? b.end : h->id_base;
+  const int64_t g = ids_next(h, n);
+  if (b.row0.empty() || g != cont) {
+    b.row0.push_back((uint32_t)row_first);
+    b.gid0.push_back((uint32_t)g);
+    b.dirty = true;
+  }
+  b.end = g + n;
+  b.next = -1;
+}
+// the table on the device: a fresh allocation per change (hipFree waits for whatever still reads the old one)
+static void ids_upload(hx_index* h) {
+  auto& b = h->ids;
+  if (!b.dirty) return;
+  const int nb = (int)b.row0.size();
+  uint32_t* nd = nullptr;
+  const int cap = std::max(nb, 1);
+  HX_HIP(hipMalloc((void**)&nd, (size_t)cap * 8));
+  if (nb) {
+    HX_HIP(hipMemcpy(nd, b.row0.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
+    HX_HIP(hipMemcpy(nd + cap, b.gid0.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
+  }
+  if (b.dev) HX_HIP(hipFree(b.dev));
+  b.dev = nd;
+  b.dev_cap = cap;
+  b.dirty = false;
+}
+// keys a stage hands out: internal ids -> global ids, in place
+static void remap_out(hx_index* h, uint64_t* keys, int64_t n, hipStream_t st) {
+  if (n <= 0 || ids_identity(h)) return;
+  ids_upload(h);
+  launch_remap_ids(keys, keys, n, h->ids.dev, h->ids.dev + h->ids.dev_cap, (int)h->ids.row0.size(),
+                   (uint32_t)h->id_base, (uint32_t)h->n, 1, st);
+}
+// candidate keys a stage takes in: global ids -> internal ids (rows of other shards become empty slots)
+static const uint64_t* remap_in(hx_index* h, const uint64_t* keys, int64_t n, hipStream_t st) {
+  if (n <= 0 || ids_identity(h)) return keys;
+  ids_upload(h);
+  uint64_t* tmp = (uint64_t*)h->ws.get(WS_ID_IN, (size_t)n * 8);
+  launch_remap_ids(keys, tmp, n, h->ids.dev, h->ids.dev + h->ids.dev_cap, (int)h->ids.row0.size(),
+                   (uint32_t)h->id_base, (uint32_t)h->n, 0, st);
+  return tmp;
+}
+// a failed or finished add consumes the id named by hx_set_next_id
+struct NextIdGuard {
+  hx_index* h;
+  ~NextIdGuard() { h->ids.next = -1; }
+};
 
 // ---------------------------------------------------------------------------------
 // per-search candidate geometry
@@ -953,6 +1074,7 @@ static bool sparse_resolve(hx_index* h, const int64_t* q_indptr, const int32_t* 
   std::vector<int> sel;
   for (int b = 0; b < B; ++b) {
     HX_CHECK(flag[(size_t)b] != 2, "sparse query values must be finite");
+    HX_CHECK(flag[(size_t)b] != 3, "sparse query term ids must be non-negative and strictly ascending within a query");
     if (flag[(size_t)b] || fail[(size_t)b]) sel.push_back(b);
   }
   if (sel.empty()) return false;
@@ -1184,6 +1306,7 @@ int hx_destroy(hx_index* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->pin) (void)hipHostFree(h->pin);
+  if (h->ids.dev) (void)hipFree(h->ids.dev);
   h->ws.release();
   delete h;
   HX_CATCH
@@ -1204,6 +1327,7 @@ static void add_dense_host(hx_index* h, const float* rows_host, int64_t n) {
   if (n == 0) return;
   HX_CHECK(rows_host, "rows is NULL");
   HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
+  (void)ids_next(h, n);
   h->set_device();
   reserve_rows(h, h->n + n);
   const int64_t CH = 65536;
@@ -1221,6 +1345,33 @@ static void add_dense_host(hx_index* h, const float* rows_host, int64_t n) {
     h->n = n_before;   // all or nothing
     throw;
   }
+  ids_commit(h, n_before, n);
+}
+
+// the same for rows that already lie on the device (an encoder's output): read in place, no staging copy
+static void add_dense_dev(hx_index* h, const float* rows_dev, int64_t n, hipStream_t st) {
+  HX_CHECK(n >= 0, "n < 0");
+  if (n == 0) return;
+  HX_CHECK(rows_dev, "rows is NULL");
+  HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
+  (void)ids_next(h, n);
+  h->set_device();
+  HX_HIP(hipStreamSynchronize(st));   // reserve_rows may move the stores; the caller's rows must be complete anyway
+  reserve_rows(h, h->n + n);
+  const int64_t CH = 65536;
+  const int64_t n_before = h->n;
+  try {
+    for (int64_t r0 = 0; r0 < n; r0 += CH) {
+      const int64_t m = std::min(CH, n - r0);
+      prep_rows_device(h, rows_dev + r0 * h->dim, m, st);
+      h->n += m;
+    }
+    HX_HIP(hipStreamSynchronize(st));
+  } catch (...) {
+    h->n = n_before;   // all or nothing
+    throw;
+  }
+  ids_commit(h, n_before, n);
 }
 
 // Largest |value| a sparse vector may hold: products q_t * d_t then stay far inside fp32.
@@ -1283,6 +1434,7 @@ static void add_sparse_host(hx_index* h, const int64_t* indptr, const int32_t* i
 int hx_add_dense(hx_index* h, const float* rows_host, int64_t n) {
   HX_TRY
   HX_CHECK(h, "index is NULL");
+  NextIdGuard guard{h};
   add_dense_host(h, rows_host, n);
   HX_CATCH
 }
@@ -1290,21 +1442,18 @@ int hx_add_dense(hx_index* h, const float* rows_host, int64_t n) {
 int hx_add_dense_dev(hx_index* h, const float* rows_dev, int64_t n, void* stream) {
   HX_TRY
   HX_CHECK(h, "index is NULL");
-  HX_CHECK(n >= 0, "n < 0");
-  if (n == 0) return 0;
-  HX_CHECK(rows_dev, "rows is NULL");
-  HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
-  h->set_device();
-  hipStream_t st = (hipStream_t)stream;
-  HX_HIP(hipStreamSynchronize(st));   // reserve_rows may move the stores; the caller's rows must be complete anyway
-  reserve_rows(h, h->n + n);
-  const int64_t CH = 65536;
-  for (int64_t r0 = 0; r0 < n; r0 += CH) {   // the encoder's output is read where it lies: no staging copy
-    const int64_t m = std::min(CH, n - r0);
-    prep_rows_device(h, rows_dev + r0 * h->dim, m, st);
-    h->n += m;
-  }
-  HX_HIP(hipStreamSynchronize(st));
+  NextIdGuard guard{h};
+  add_dense_dev(h, rows_dev, n, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_set_next_id(hx_index* h, int64_t first_id) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  HX_CHECK(first_id >= 0 && first_id < 0xFFFFFFFFll, "id out of range [0, 2^32 - 1)");
+  const int64_t cont = h->ids.end >= 0 ? h->ids.end : h->id_base;
+  HX_CHECK(first_id >= cont, "hx_set_next_id: the ids of a shard must ascend with its rows");
+  h->ids.next = first_id;
   HX_CATCH
 }
 
@@ -1315,21 +1464,19 @@ int hx_add_sparse(hx_index* h, const int64_t* indptr, const int32_t* idx, const 
   HX_CATCH
 }
 
-int hx_add_rows(hx_index* h, const float* rows_host, const int64_t* indptr, const int32_t* idx, const float* val,
-                int64_t n) {
-  HX_TRY
-  HX_CHECK(h, "index is NULL");
+// a chunk's dense and sparse vectors are committed together: a failure of either leaves the index as it was
+static void add_rows_atomic(hx_index* h, const int64_t* indptr, const int32_t* idx, const float* val, int64_t n,
+                            const std::function<void()>& add_dense) {
   HX_CHECK(n >= 0, "n < 0");
-  if (n == 0) return 0;
-  HX_CHECK(rows_host, "rows is NULL");
+  if (n == 0) return;
   HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
-  // a chunk's dense and sparse vectors are committed together: a failure of either leaves the index as it was
+  (void)ids_next(h, n);
   const int64_t sp_rows0 = h->sp_rows, nnz0 = h->nnz;
   const bool stale0 = h->sparse_stale, have0 = h->sp_have_w;
   const float lo0 = h->sp_wmin, hi0 = h->sp_wmax;
   if (indptr) add_sparse_host(h, indptr, idx, val, n);
   try {
-    add_dense_host(h, rows_host, n);
+    add_dense();
   } catch (...) {
     h->sp_rows = sp_rows0;
     h->nnz = nnz0;
@@ -1339,6 +1486,58 @@ int hx_add_rows(hx_index* h, const float* rows_host, const int64_t* indptr, cons
     h->sp_wmax = hi0;
     throw;
   }
+}
+
+int hx_add_rows(hx_index* h, const float* rows_host, const int64_t* indptr, const int32_t* idx, const float* val,
+                int64_t n) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  NextIdGuard guard{h};
+  HX_CHECK(n <= 0 || rows_host, "rows is NULL");
+  add_rows_atomic(h, indptr, idx, val, n, [&]() { add_dense_host(h, rows_host, n); });
+  HX_CATCH
+}
+
+int hx_add_rows_dev(hx_index* h, const float* rows_dev, const int64_t* indptr, const int32_t* idx, const float* val,
+                    int64_t n, void* stream) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  NextIdGuard guard{h};
+  HX_CHECK(n <= 0 || rows_dev, "rows is NULL");
+  add_rows_atomic(h, indptr, idx, val, n, [&]() { add_dense_dev(h, rows_dev, n, (hipStream_t)stream); });
+  HX_CATCH
+}
+
+// Roll the collection back to its first n_rows rows (a batch that one shard of a sharded collection could not
+// store is undone on the shards that did store it; qdrant_handler.py:190-193 upserts a batch as one request).
+int hx_truncate(hx_index* h, int64_t n_rows) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  HX_CHECK(n_rows >= 0 && n_rows <= h->n, "hx_truncate: n_rows out of range [0, count]");
+  h->set_device();
+  HX_HIP(hipDeviceSynchronize());
+  h->ids.next = -1;
+  if (n_rows == h->n && h->sp_rows <= n_rows) return 0;
+  h->n = n_rows;
+  h->q8_tile_max_rows = -1;
+  if (h->sp_rows > n_rows) {
+    int64_t nnz = 0;
+    if (n_rows > 0) HX_HIP(hipMemcpy(&nnz, h->sp_indptr + n_rows, 8, hipMemcpyDeviceToHost));
+    h->sp_rows = n_rows;
+    h->nnz = nnz;
+  }
+  // the inverted index: a base that reaches past the cut is rebuilt, the tail always is.  The weight range stays
+  // as it was: an upper bound of the remaining weights is all the select pass needs.
+  free_sparse_ix(h->sp_tail);
+  if (h->sp_base.n_docs > h->sp_rows) free_sparse_ix(h->sp_base);
+  h->sparse_stale = true;
+  auto& b = h->ids;
+  while (!b.row0.empty() && (int64_t)b.row0.back() >= n_rows) {
+    b.row0.pop_back();
+    b.gid0.pop_back();
+  }
+  b.end = b.row0.empty() ? -1 : (int64_t)b.gid0.back() + (n_rows - (int64_t)b.row0.back());
+  b.dirty = true;
   HX_CATCH
 }
 
@@ -1370,6 +1569,8 @@ int hx_synth_fill(hx_index* h, int64_t n, uint32_t seed_dense, uint32_t seed_spa
   HX_CHECK(n >= 0, "n < 0");
   if (n == 0) return 0;
   HX_CHECK(h->id_base + h->n + n < 0xFFFFFFFFll, "row ids must stay below 2^32 - 1");
+  NextIdGuard guard{h};
+  (void)ids_next(h, n);
   h->set_device();
   hipStream_t st = nullptr;
   reserve_rows(h, h->n + n);
@@ -1411,6 +1612,7 @@ int hx_synth_fill(hx_index* h, int64_t n, uint32_t seed_dense, uint32_t seed_spa
     h->n += m;
   }
   HX_HIP(hipStreamSynchronize(st));
+  ids_commit(h, row0, n);
   HX_CATCH
 }
 
@@ -1427,6 +1629,7 @@ int hx_search_dense(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, 
   HX_CHECK(h && q_dev && keys_dev && counts_dev, "NULL argument");
   h->set_device();
   search_dense(h, q_dev, B, prefix, limit, keys_dev, counts_dev, (hipStream_t)stream);
+  remap_out(h, keys_dev, (int64_t)B * limit, (hipStream_t)stream);
   HX_CATCH
 }
 
@@ -1436,17 +1639,18 @@ int hx_search_i8(hx_index* h, const float* q_dev, int32_t B, int32_t limit, uint
   HX_CHECK(h && q_dev && keys_dev && counts_dev, "NULL argument");
   h->set_device();
   search_i8(h, q_dev, B, limit, keys_dev, counts_dev, (hipStream_t)stream);
+  remap_out(h, keys_dev, (int64_t)B * limit, (hipStream_t)stream);
   HX_CATCH
 }
 
 int hx_search_sparse(hx_index* h, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
-                     const float* q_val_dev, int32_t B, int32_t max_terms, int32_t limit,
+                     const float* q_val_dev, int32_t B, int32_t limit,
                      uint64_t* keys_dev, int32_t* counts_dev, void* stream) {
   HX_TRY
   HX_CHECK(h && q_indptr_dev && keys_dev && counts_dev, "NULL argument");
-  (void)max_terms;
   h->set_device();
   search_sparse(h, q_indptr_dev, q_idx_dev, q_val_dev, B, limit, keys_dev, counts_dev, (hipStream_t)stream);
+  remap_out(h, keys_dev, (int64_t)B * limit, (hipStream_t)stream);
   HX_CATCH
 }
 
@@ -1456,16 +1660,20 @@ int hx_rescore(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, const
   HX_TRY
   HX_CHECK(h && q_dev && cand_keys_dev && keys_dev && counts_dev, "NULL argument");
   h->set_device();
-  rescore(h, q_dev, B, prefix, cand_keys_dev, cand_stride, cand_counts_dev, limit, keys_dev, counts_dev,
+  HX_CHECK(B > 0 && cand_stride >= 1 && cand_stride <= CAND_CAP, "candidate stride out of range");
+  const uint64_t* cand = remap_in(h, cand_keys_dev, (int64_t)B * cand_stride, (hipStream_t)stream);
+  rescore(h, q_dev, B, prefix, cand, cand_stride, cand_counts_dev, limit, keys_dev, counts_dev,
           (hipStream_t)stream);
+  remap_out(h, keys_dev, (int64_t)B * limit, (hipStream_t)stream);
   HX_CATCH
 }
 
 // Workspace of the index-free entries (hx_rrf, hx_merge, hx_h1_fuse): one per (device, calling thread), so two
-// threads fusing lists on one device never share scratch (buffers of one thread are reused in stream order).
+// threads fusing lists on one device never share scratch (buffers of one thread are reused in stream order); a
+// thread that exits returns its workspaces to the pool (hx::WorkspacePool above).
 static hx::Workspace& static_ws(int device) {
-  static thread_local std::map<int, hx::Workspace> w;
-  return w[device];
+  static thread_local hx::ThreadWorkspaces w;
+  return w.get(device);
 }
 
 int hx_rrf(int32_t device, const uint64_t* a, int32_t as, const int32_t* ac, const uint64_t* b, int32_t bs,
@@ -1518,6 +1726,7 @@ int hx_h1_local(hx_index* h, const float* qd, const int64_t* qip, const int32_t*
   });
   const bool sp_patched = sparse_resolve(h, qip, qix, qv, B, sparse_limit, S, Sc, st);
   if (patched || sp_patched) pack();
+  remap_out(h, keys_dev, (int64_t)B * (dense_limit + sparse_limit), st);
   HX_CATCH
 }
 
@@ -1543,6 +1752,7 @@ int hx_h1_local_async(hx_index* h, const float* qd, const int64_t* qip, const in
   }, true);
   h->sp_sum_pending = false;                       // nobody will call sparse_resolve for this batch
   h->sp_sum_fetched = false;
+  remap_out(h, keys_dev, (int64_t)B * L2, st);
   launch_flag_row(nfail, spsum, keys_dev + (size_t)B * L2, L2, st);
   HX_CATCH
 }
@@ -1582,14 +1792,14 @@ int hx_unpack(int32_t device, const uint64_t* keys_dev, int64_t n, float* scores
 }
 
 int hx_hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix,
-                        const float* qv, int32_t B, int32_t max_terms, const hx_params* p,
+                        const float* qv, int32_t B, const hx_params* p,
                         uint64_t* keys_dev, int32_t* counts_dev, void* stream) {
   HX_TRY
   HX_CHECK(h && qd && qip && keys_dev && counts_dev, "NULL argument");
-  (void)max_terms;
   check_params(p);
   h->set_device();
   hybrid_query_dev(h, qd, qip, qix, qv, B, p, keys_dev, counts_dev, (hipStream_t)stream);
+  remap_out(h, keys_dev, (int64_t)B * p->final_limit, (hipStream_t)stream);
   HX_CATCH
 }
 
@@ -1636,6 +1846,7 @@ int hx_hybrid_query_host(hx_index* h, const float* qd, const int64_t* qip, const
     HX_HIP(hipMemcpyAsync(dv, sv.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
   }
   hybrid_query_dev(h, dq, dip, dix, dv, B, p, ok, oc, st);
+  remap_out(h, ok, (int64_t)B * L, st);
   launch_unpack(ok, (int64_t)B * L, osc, oid, st);
   HX_HIP(hipMemcpyAsync(scores, osc, (size_t)B * L * 4, hipMemcpyDeviceToHost, st));
   HX_HIP(hipMemcpyAsync(ids, oid, (size_t)B * L * 8, hipMemcpyDeviceToHost, st));
@@ -1726,11 +1937,11 @@ int hx_debug_row(hx_index* h, int32_t which, int64_t row, void* out_host) {
 // the doc-major sparse CSR; the inverted index is rebuilt on load (K9, ~1.4 s per 10^9 postings).
 namespace {
 struct HxFileHeader {
-  char magic[8];             // "HXIDX\0\0\1"
-  int32_t dim, n_pre, psize[3], reserved;
+  char magic[8];             // "HXIDX\0\0\2" (version 1: no id-block table, n_blocks reads 0)
+  int32_t dim, n_pre, psize[3], n_blocks;
   int64_t id_base, n, sp_rows, nnz;
 };
-const char HX_MAGIC[8] = {'H', 'X', 'I', 'D', 'X', 0, 0, 1};
+const char HX_MAGIC[8] = {'H', 'X', 'I', 'D', 'X', 0, 0, 2};
 constexpr size_t HX_IO_CHUNK = (size_t)64 << 20;
 
 struct File {
@@ -1771,7 +1982,12 @@ int hx_save(hx_index* h, const char* path) {
   hd.n = h->n;
   hd.sp_rows = h->sp_rows;
   hd.nnz = h->nnz;
+  hd.n_blocks = (int32_t)h->ids.row0.size();
   HX_CHECK(fwrite(&hd, sizeof hd, 1, fl.f) == 1, "short write");
+  if (hd.n_blocks) {         // the id-block table: row0 column, then gid0 column
+    HX_CHECK(fwrite(h->ids.row0.data(), 4, (size_t)hd.n_blocks, fl.f) == (size_t)hd.n_blocks, "short write");
+    HX_CHECK(fwrite(h->ids.gid0.data(), 4, (size_t)hd.n_blocks, fl.f) == (size_t)hd.n_blocks, "short write");
+  }
   std::vector<char> buf(HX_IO_CHUNK);
   const size_t n = (size_t)h->n;
   dev_to_file(fl.f, h->dense, n * h->dim_pad * 4, buf);
@@ -1795,7 +2011,9 @@ int hx_load(const char* path, int32_t device, hx_index** out) {
   File fl(path, "rb");
   HxFileHeader hd{};
   HX_CHECK(fread(&hd, sizeof hd, 1, fl.f) == 1, "short read: not an index file");
-  HX_CHECK(memcmp(hd.magic, HX_MAGIC, 8) == 0, "not an hx index file (bad magic / version)");
+  HX_CHECK(memcmp(hd.magic, HX_MAGIC, 7) == 0 && (hd.magic[7] == 1 || hd.magic[7] == 2),
+           "not an hx index file (bad magic / version)");
+  if (hd.magic[7] == 1) hd.n_blocks = 0;     // version 1: ids are id_base + row
   // The header is not trusted: every size is checked against the limits of the add path and against the
   // length of the file BEFORE anything is allocated (a corrupt count must not become a huge hipMalloc).
   HX_CHECK(hd.n >= 0 && hd.sp_rows >= 0 && hd.nnz >= 0 && hd.n_pre >= 0 && hd.n_pre <= 3, "corrupt header");
@@ -1810,18 +2028,41 @@ int hx_load(const char* path, int32_t device, hx_index** out) {
       per_row += (int64_t)hd.psize[p] * 4;
     }
     if (hd.n_pre > 0) per_row += (int64_t)hd.psize[0] * 2;
-    int64_t want = (int64_t)sizeof hd + hd.n * per_row;
+    HX_CHECK(hd.n_blocks >= 0 && hd.n_blocks <= hd.n, "corrupt header: id blocks");
+    int64_t want = (int64_t)sizeof hd + (int64_t)hd.n_blocks * 8 + hd.n * per_row;
     if (hd.sp_rows > 0) want += (hd.sp_rows + 1) * 8 + hd.nnz * 8;
     HX_CHECK(fseek(fl.f, 0, SEEK_END) == 0, "cannot seek");
     const int64_t have = (int64_t)ftell(fl.f);
     HX_CHECK(fseek(fl.f, (long)sizeof hd, SEEK_SET) == 0, "cannot seek");
     HX_CHECK(have == want, "index file length does not match its header (truncated or corrupt)");
   }
+  // the id-block table: both columns ascend strictly from row 0, a block's ids end before the next block's begin,
+  // the last id stays below 2^32 - 1
+  std::vector<uint32_t> row0((size_t)hd.n_blocks), gid0((size_t)hd.n_blocks);
+  if (hd.n_blocks) {
+    HX_CHECK(fread(row0.data(), 4, row0.size(), fl.f) == row0.size(), "short read: truncated index file");
+    HX_CHECK(fread(gid0.data(), 4, gid0.size(), fl.f) == gid0.size(), "short read: truncated index file");
+    HX_CHECK(row0[0] == 0, "corrupt index file: id blocks");
+    for (size_t k = 0; k < row0.size(); ++k) {
+      const int64_t len = (k + 1 < row0.size() ? (int64_t)row0[k + 1] : hd.n) - (int64_t)row0[k];
+      HX_CHECK(len >= 1 && (int64_t)gid0[k] + len < 0xFFFFFFFFll, "corrupt index file: id blocks");
+      HX_CHECK(k + 1 == row0.size() || (int64_t)gid0[k] + len <= (int64_t)gid0[k + 1], "corrupt index file: id blocks");
+    }
+  } else if (hd.n > 0) {
+    row0.assign(1, 0u);
+    gid0.assign(1, (uint32_t)hd.id_base);
+  }
   hx_index* h = nullptr;
   const int rc = hx_create(hd.dim, hd.psize, hd.n_pre, device, hd.id_base, &h);
   if (rc != 0) return rc;
   try {
     h->set_device();
+    if (!row0.empty()) {
+      h->ids.end = (int64_t)gid0.back() + (hd.n - (int64_t)row0.back());
+      h->ids.row0.swap(row0);
+      h->ids.gid0.swap(gid0);
+      h->ids.dirty = true;
+    }
     std::vector<char> buf(HX_IO_CHUNK);
     const size_t n = (size_t)hd.n;
     reserve_rows(h, hd.n);
@@ -1845,6 +2086,30 @@ int hx_load(const char* path, int32_t device, hx_index** out) {
       int hbad = 0;
       HX_HIP(hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost));
       HX_CHECK(hbad == 0, "corrupt index file: sparse CSR is inconsistent");
+      // term ids unique within a row (hx_add_sparse enforces it; the exact pass finds a query term with ONE ballot)
+      constexpr int LONG_CAP = 4096;
+      int64_t* long_rows = (int64_t*)h->ws.get(WS_LONG_ROWS, (size_t)LONG_CAP * 8 + 8);
+      int* n_long = (int*)(long_rows + LONG_CAP);
+      HX_HIP(hipMemset(n_long, 0, 4));
+      launch_csr_unique(h->sp_indptr, h->sp_idx, hd.sp_rows, bad, long_rows, LONG_CAP, n_long, nullptr);
+      int hn_long = 0;
+      HX_HIP(hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost));
+      HX_HIP(hipMemcpy(&hn_long, n_long, 4, hipMemcpyDeviceToHost));
+      HX_CHECK(hbad == 0, "corrupt index file: a sparse vector repeats a term id");
+      HX_CHECK(hn_long <= LONG_CAP, "corrupt index file: too many oversized sparse vectors");
+      if (hn_long > 0) {            // the few rows too long for the wave compare: sorted on the host
+        std::vector<int64_t> rows((size_t)hn_long);
+        HX_HIP(hipMemcpy(rows.data(), long_rows, rows.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<int32_t> ids;
+        for (int64_t r : rows) {
+          int64_t be[2];
+          HX_HIP(hipMemcpy(be, h->sp_indptr + r, 16, hipMemcpyDeviceToHost));
+          ids.resize((size_t)(be[1] - be[0]));
+          HX_HIP(hipMemcpy(ids.data(), h->sp_idx + be[0], ids.size() * 4, hipMemcpyDeviceToHost));
+          std::sort(ids.begin(), ids.end());
+          HX_CHECK(std::adjacent_find(ids.begin(), ids.end()) == ids.end(), "corrupt index file: a sparse vector repeats a term id");
+        }
+      }
       track_weights_dev(h, h->sp_val, hd.nnz, nullptr);
       h->sp_rows = hd.sp_rows;
       h->nnz = hd.nnz;

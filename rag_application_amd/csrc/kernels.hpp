@@ -134,6 +134,9 @@ void launch_scan_init(float* tau, int* cnt, int* ovf, int* kept, int B, int cnt0
 void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st);
 void launch_flag_row(const int* nfail, const int* spsum, uint64_t* row, int len, hipStream_t st);
+// internal id (id_base + local row) <-> global insertion-order id through the index's block table (select.hip)
+void launch_remap_ids(const uint64_t* in, uint64_t* out, int64_t n, const uint32_t* row0, const uint32_t* gid0, int nb,
+                      uint32_t id_base, uint32_t n_rows, int to_global, hipStream_t st);
 
 // ---- prep.hip ----------------------------------------------------------------
 // Derive the stored vectors of rows [0,n) of `raw` (fp32 [n x dim]):
@@ -203,7 +206,8 @@ struct SparsePrepArgs {
   int32_t* q_ti[2];            // [B x SP_TMAX] live-term index per view, -1 = absent
   float* q_qs;                 // [B x SP_TMAX] query weight * scale
   int* q_margin;               // [B]
-  int* q_flag;                 // [B] 0 ok, 1 = needs the document-at-a-time path, 2 = invalid (non-finite weight)
+  int* q_flag;                 // [B] 0 ok, 1 = needs the document-at-a-time path, 2 = invalid (non-finite weight),
+                               //     3 = invalid (term ids not strictly ascending, or negative)
   unsigned long long* q_work;  // [B] postings of the query's terms (both views): launch order, profile
   unsigned long long* stat_postings;   // optional: += sum of q_work
 };
@@ -287,6 +291,12 @@ void launch_sparse_range(const SparseRangeArgs& a, hipStream_t st);
 void launch_minmax_f32(const float* val, int64_t n, float* mm, hipStream_t st);
 // *bad = 1 unless indptr[0] = 0, indptr is monotone up to indptr[n_rows] = nnz and every idx is >= 0
 void launch_csr_check(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int64_t nnz, int* bad, hipStream_t st);
+// term ids unique within every row (what hx_add_sparse enforces and k_sparse_rescore's one-ballot-per-term relies
+// on): *bad = 1 on a duplicate.  Rows longer than CSR_UNIQUE_WAVE_MAX terms are not compared on the device: their
+// indices go to long_rows[0, *n_long) (at most long_cap are listed; *n_long keeps counting) for the host to check.
+constexpr int CSR_UNIQUE_WAVE_MAX = 2048;
+void launch_csr_unique(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int* bad, int64_t* long_rows,
+                       int long_cap, int* n_long, hipStream_t st);
 
 // ---- spbuild.hip -------------------------------------------------------------
 struct SparseBuildOut {

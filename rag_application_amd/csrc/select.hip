@@ -494,6 +494,50 @@ void launch_flag_row(const int* nfail, const int* spsum, uint64_t* row, int len,
   HX_HIP(hipGetLastError());
 }
 
+// Insertion-order ids under row sharding (engine.hip IdBlocks): a shard's rows arrive in blocks, block k = local
+// rows [row0[k], row0[k + 1]) with global ids gid0[k], gid0[k] + 1, ...; both columns ascend, so the map between the
+// engine's internal id (id_base + local row) and the global id is monotone and a sorted list stays sorted.
+//   to_global = 1: keys carry internal ids -> global ids, in place (out == keys allowed);
+//   to_global = 0: keys carry global ids -> internal ids; ids of other shards (and empty slots) give key 0.
+__device__ __forceinline__ int last_le(const uint32_t* col, int nb, uint32_t v) {   // last k with col[k] <= v, -1 if none
+  int lo = 0, hi = nb;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo - 1;
+}
+__global__ void k_remap_ids(const uint64_t* in, uint64_t* out, int64_t n, const uint32_t* row0, const uint32_t* gid0,
+                            int nb, uint32_t id_base, uint32_t n_rows, int to_global) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = in[i];
+  uint64_t r = 0ull;
+  if (k != 0ull) {
+    const uint32_t id = key_id(k);
+    if (to_global) {
+      const uint32_t row = id - id_base;
+      const int b = last_le(row0, nb, row);
+      if (b >= 0 && id >= id_base && row < n_rows) r = (k & 0xFFFFFFFF00000000ull) | (uint64_t)(0xFFFFFFFFu - (gid0[b] + (row - row0[b])));
+    } else {
+      const int b = last_le(gid0, nb, id);
+      if (b >= 0) {
+        const uint32_t row = row0[b] + (id - gid0[b]);
+        const uint32_t end = b + 1 < nb ? row0[b + 1] : n_rows;
+        if (row < end) r = (k & 0xFFFFFFFF00000000ull) | (uint64_t)(0xFFFFFFFFu - (id_base + row));
+      }
+    }
+  }
+  out[i] = r;
+}
+void launch_remap_ids(const uint64_t* in, uint64_t* out, int64_t n, const uint32_t* row0, const uint32_t* gid0, int nb,
+                      uint32_t id_base, uint32_t n_rows, int to_global, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_remap_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n, row0, gid0, nb,
+                     id_base, n_rows, to_global);
+  HX_HIP(hipGetLastError());
+}
+
 void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_fill<int>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);

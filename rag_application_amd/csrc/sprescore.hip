@@ -47,15 +47,20 @@ __global__ __launch_bounds__(256) void k_sparse_prep(SparsePrepArgs a) {
   const int T = (int)(a.q_indptr[q + 1] - qb);
   int flag = 0;
   // weights: finite (else the query is invalid), positive (else the integer pass cannot bracket the score)
-  bool bad = false, nonpos = false;
+  // term ids: strictly ascending (the exact score is a running fp32 sum in ascending term id, upstream's order:
+  // another order gives other score bits; a repeated id would be counted twice) and non-negative
+  bool bad = false, nonpos = false, disorder = false;
   double sum = 0.0;
   for (int j = lane; j < T; j += 64) {
     const float v = a.q_val[qb + j];
     bad |= !(__builtin_fabsf(v) <= 3.0e38f);
     nonpos |= !(v > 0.0f);
     sum += (double)v;
+    const int32_t id = a.q_idx[qb + j];
+    disorder |= id < 0 || (j > 0 && !(a.q_idx[qb + j - 1] < id));
   }
   if (__ballot(bad)) flag = 2;
+  else if (__ballot(disorder)) flag = 3;
   else if (__ballot(nonpos) || a.index_nonpos || T > SP_TMAX) flag = 1;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);   // same value in every lane
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256) void k_sparse_summary(const int* flag, const i
   int bad = 0, inv = 0;
   for (int b = threadIdx.x; b < B; b += 256) {
     bad += (flag[b] != 0 || fail[b] != 0) ? 1 : 0;
-    inv += flag[b] == 2 ? 1 : 0;
+    inv += flag[b] >= 2 ? 1 : 0;
   }
   if (bad) atomicAdd(&s_bad, bad);
   if (inv) atomicAdd(&s_inv, inv);
@@ -390,6 +395,45 @@ void launch_csr_check(const int64_t* indptr, const int32_t* idx, int64_t n_rows,
   const int64_t m = n_rows > nnz ? n_rows : nnz;
   if (m <= 0) return;
   hipLaunchKernelGGL(k_csr_check, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, indptr, idx, n_rows, nnz, bad);
+  HX_HIP(hipGetLastError());
+}
+
+// term ids unique within a row, one wave per row: the row's chunks of 64 ids against each other (len^2 / 64 lane
+// reads: rows up to CSR_UNIQUE_WAVE_MAX ids; longer ones are listed for the host)
+__global__ __launch_bounds__(256) void k_csr_unique(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int* bad,
+                                                    int64_t* long_rows, int long_cap, int* n_long) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int64_t b = indptr[row], e = indptr[row + 1];
+  const int64_t len = e - b;
+  if (len < 2) return;
+  if (len > CSR_UNIQUE_WAVE_MAX) {
+    if (lane == 0) {
+      const int p = atomicAdd(n_long, 1);
+      if (p < long_cap) long_rows[p] = row;
+    }
+    return;
+  }
+  bool dup = false;
+  for (int64_t c = b; c < e; c += 64) {
+    const int32_t mine = c + lane < e ? idx[c + lane] : -1 - lane;          // padding lanes: distinct negatives
+    for (int64_t c2 = c; c2 < e; c2 += 64) {
+      const int32_t other = c2 + lane < e ? idx[c2 + lane] : -100 - lane;
+      const int m = (int)((e - c2) < 64 ? (e - c2) : 64);
+      for (int j = 0; j < m; ++j) {
+        const int32_t v = __builtin_amdgcn_readlane(other, j);
+        dup |= (mine == v) && !(c2 == c && j == lane);
+      }
+    }
+  }
+  if (__ballot(dup) && lane == 0) *bad = 1;
+}
+void launch_csr_unique(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int* bad, int64_t* long_rows,
+                       int long_cap, int* n_long, hipStream_t st) {
+  if (n_rows <= 0) return;
+  hipLaunchKernelGGL(k_csr_unique, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, indptr, idx, n_rows, bad,
+                     long_rows, long_cap, n_long);
   HX_HIP(hipGetLastError());
 }
 

@@ -31,6 +31,24 @@ class ShardedIndex:
         if ops is None:
             from . import engine as ops  # HIP kernels
         self.ops = ops
+        # A local stage that raises must not leave the other ranks alone inside the stage's all-gather: the error is
+        # kept, this rank goes on with EMPTY lists of the right shape (so every collective of the query still
+        # happens, on every rank, in the same order), and the caller exchanges `take_error()` at the end of the
+        # call -- a failed rank makes the whole call fail on every rank (sharded.ShardedCollection.search).
+        self.err: Optional[BaseException] = None
+
+    def take_error(self) -> Optional[BaseException]:
+        e, self.err = self.err, None
+        return e
+
+    def _local(self, name: str, B: int, width: int, like: torch.Tensor, *args, counts: bool = True):
+        if self.err is None:
+            try:
+                return getattr(self.local, name)(*args)
+            except Exception as e:            # kept for the status exchange; the collectives go on
+                self.err = e
+        k = torch.zeros((B, width), dtype=torch.int64, device=like.device)
+        return (k, torch.zeros((B,), dtype=torch.int32, device=like.device)) if counts else k
 
     # -- exchange ---------------------------------------------------------------------
     def gather(self, keys: torch.Tensor) -> torch.Tensor:
@@ -61,20 +79,20 @@ class ShardedIndex:
 
     # -- stages: global lists, replicated on every rank ----------------------------------
     def search_dense(self, q, limit, prefix=0):
-        k, c = self.local.search_dense(q, limit, prefix)
+        k, c = self._local("search_dense", q.shape[0], limit, q, q, limit, prefix)
         return (k, c) if self.world == 1 else self._global(k, limit)
 
     def search_i8(self, q, limit):
-        k, c = self.local.search_i8(q, limit)
+        k, c = self._local("search_i8", q.shape[0], limit, q, q, limit)
         return (k, c) if self.world == 1 else self._global(k, limit)
 
     def search_sparse(self, q_indptr, q_idx, q_val, limit):
-        k, c = self.local.search_sparse(q_indptr, q_idx, q_val, limit)
+        k, c = self._local("search_sparse", q_indptr.shape[0] - 1, limit, q_indptr, q_indptr, q_idx, q_val, limit)
         return (k, c) if self.world == 1 else self._global(k, limit)
 
     def rescore(self, q, cand_keys, cand_counts, limit, prefix=0):
         # each rank scores the candidates that live in its shard (others are skipped)
-        k, c = self.local.rescore(q, cand_keys, cand_counts, limit, prefix)
+        k, c = self._local("rescore", q.shape[0], limit, q, q, cand_keys, cand_counts, limit, prefix)
         return (k, c) if self.world == 1 else self._global(k, limit)
 
     # -- whole queries -----------------------------------------------------------------------
@@ -82,13 +100,14 @@ class ShardedIndex:
                   rrf_k=2.0, rank_base=0):
         if hasattr(self.local, "h1_local") and hasattr(self.ops, "h1_fuse"):
             # two ABI calls around the one exchange of the step: no per-stage host work in between
-            mine = self.local.h1_local(q, q_indptr, q_idx, q_val, dense_limit, sparse_limit)
+            mine = self._local("h1_local", q.shape[0], dense_limit + sparse_limit, q, q, q_indptr, q_idx, q_val,
+                               dense_limit, sparse_limit, counts=False)
             allk = mine if self.world == 1 else self.gather_raw(mine)
             return self.ops.h1_fuse(allk, self.world, dense_limit, sparse_limit, limit, rrf_k, rank_base)
         # sparse first: the dense stage ends with a host read of its failure flags, and the device
         # should not sit idle behind that read with the sparse stage still to be enqueued
-        sk, sc = self.local.search_sparse(q_indptr, q_idx, q_val, sparse_limit)
-        dk, dc = self.local.search_dense(q, dense_limit)
+        sk, sc = self._local("search_sparse", q.shape[0], sparse_limit, q, q_indptr, q_idx, q_val, sparse_limit)
+        dk, dc = self._local("search_dense", q.shape[0], dense_limit, q, q, dense_limit)
         if self.world > 1:  # one exchange carries both lists
             allk = self.gather(torch.cat([dk, sk], dim=1)).reshape(q.shape[0], self.world, -1)
             dk, dc = self.ops.merge(allk[:, :, :dense_limit].reshape(q.shape[0], -1), None, dense_limit, False)
@@ -127,7 +146,15 @@ class H1Pipeline:
     flagged (a retry or the exact path was needed: rare) is redone through the synchronous path, by all ranks
     alike, when it is verified -- at the latest in `wait()`.  The returned tensors are valid once `wait()`
     has passed.  With one rank, or without a HIP device (the gloo tests), there is no side stream and the
-    same steps run in sequence; without `h1_local_async` it degenerates to `ShardedIndex.hybrid_h1`."""
+    same steps run in sequence; without `h1_local_async` it degenerates to `ShardedIndex.hybrid_h1`.
+
+    The input tensors of a batch are kept (not copied) until its flags have been looked at -- up to `depth` + 1
+    submits later, or `wait()`: a flagged batch is redone from them, so the caller must not refill them in place
+    before that.  The returned tensors are allocated on the side stream and handed to the submitting stream
+    (`record_stream`): the caching allocator will not reuse them for a later gather while a consumer on the
+    submitting stream may still read them.
+    Hardware status: over RCCL this pipeline has run with ONE rank per box only (scripts/nccl_one_rank.py); with more
+    ranks it has run over gloo (CPU tests, 2-4 ranks sharing one GPU).  DESIGN.md section 7 says so."""
 
     def __init__(self, sh: ShardedIndex, dense_limit=100, sparse_limit=100, limit=10, rrf_k=2.0, rank_base=0,
                  depth: int = 2, force_side_stream: bool = False):
@@ -175,6 +202,9 @@ class H1Pipeline:
                 done = torch.cuda.Event()
                 done.record()
             mine.record_stream(self.side)
+            main = torch.cuda.current_stream()
+            for t in out:                       # made on the side stream, consumed on the submitting one
+                t.record_stream(main)
         else:
             out, host = self._exchange_and_fuse(mine, B)
         self.pending.append((done, host, (q, q_indptr, q_idx, q_val), out))

@@ -133,8 +133,16 @@ class HxIndex:
         sp_val = np.ascontiguousarray(sp_val, dtype=np.float32)
         if sp_indptr.shape[0] != n + 1:
             raise ValueError("sparse indptr must have n+1 entries")
-        check(_lib.lib().hx_add_sparse(self._h, _ptr(sp_indptr), _ptr(sp_idx), _ptr(sp_val), n))
-        check(_lib.lib().hx_add_dense_dev(self._h, _ptr(dense), n, _stream()))
+        # committed together or not at all, like `add` (hx_add_rows_dev)
+        check(_lib.lib().hx_add_rows_dev(self._h, _ptr(dense), _ptr(sp_indptr), _ptr(sp_idx), _ptr(sp_val), n, _stream()))
+
+    def set_next_id(self, first_id: int):
+        """Row sharding: the next add's rows get the global ids first_id, first_id + 1, ... (hx_set_next_id)."""
+        check(_lib.lib().hx_set_next_id(self._h, int(first_id)))
+
+    def truncate(self, n_rows: int):
+        """Roll back to the first n_rows rows (hx_truncate)."""
+        check(_lib.lib().hx_truncate(self._h, int(n_rows)))
 
     def synth_fill(self, n: int, seed_dense: int, seed_sparse: int = 0, tables=None):
         if tables is not None:
@@ -202,7 +210,7 @@ class HxIndex:
         q_val = _need_cuda(q_val, torch.float32, "q_val")
         B = q_indptr.shape[0] - 1
         keys, cnt = self._out(B, limit)
-        check(_lib.lib().hx_search_sparse(self._h, _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, 0, limit,
+        check(_lib.lib().hx_search_sparse(self._h, _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, limit,
                                           _ptr(keys), _ptr(cnt), _stream()))
         return keys, cnt
 
@@ -253,7 +261,7 @@ class HxIndex:
         q_val = _need_cuda(q_val, torch.float32, "q_val")
         B = q.shape[0]
         keys, cnt = self._out(B, params.final_limit)
-        check(_lib.lib().hx_hybrid_query_dev(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, 0,
+        check(_lib.lib().hx_hybrid_query_dev(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B,
                                              C.byref(params), _ptr(keys), _ptr(cnt), _stream()))
         return keys, cnt
 

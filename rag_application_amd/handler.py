@@ -24,7 +24,7 @@ import numpy as np
 
 from . import engine as _engine
 from . import filters as _filters
-from ._lib import HX_MODE_TREE
+from ._lib import HX_MODE_H1, HX_MODE_TREE
 
 
 @dataclass
@@ -61,10 +61,14 @@ def _sparse_parts(sv):
 
 
 class _Collection:
-    def __init__(self, dim, msizes, device):
+    """One user collection: the engine index (anything with HxIndex's add / hybrid_query_host / count / save /
+    close: sharded.ShardedHandler plugs in a row-sharded one) plus the point ids and payloads, which never cross
+    the C ABI and are indexed by the engine's row id = insertion order."""
+
+    def __init__(self, dim, msizes, device, index=None):
         self.dim = dim
         self.msizes = tuple(msizes)
-        self.index = _engine.HxIndex(dim, self.msizes, device=device)
+        self.index = index if index is not None else _engine.HxIndex(dim, self.msizes, device=device)
         self.ids: List[str] = []
         self.payloads: List[Dict[str, Any]] = []
         self.sparse_enabled = True
@@ -81,13 +85,14 @@ class _Collection:
                        "ids": self.ids, "payloads": self.payloads}, f)
 
     @classmethod
-    def load(cls, base: str, device: int):
+    def load(cls, base: str, device: int, index_loader=None):
         with open(base + ".json") as f:
             meta = json.load(f)
         self = cls.__new__(cls)
         self.dim = int(meta["dim"])
         self.msizes = tuple(meta["msizes"])
-        self.index = _engine.HxIndex.load(base + ".hx", device=device)
+        self.index = (index_loader(base + ".hx", meta) if index_loader is not None
+                      else _engine.HxIndex.load(base + ".hx", device=device))
         self.ids = list(meta["ids"])
         self.payloads = list(meta["payloads"])
         self.sparse_enabled = bool(meta["sparse_enabled"])
@@ -134,17 +139,10 @@ class QdrantHandler:
             def make():
                 old = self._collections.pop(user_id, None)
                 if old is not None:
-                    old.close()
-                base = self._base(user_id)
-                if base and not force_recreate and os.path.exists(base + ".hx") and os.path.exists(base + ".json"):
-                    col = _Collection.load(base, self.device)
-                    if col.dim != int(dense_vector_size):
-                        col.close()
-                        raise ValueError("stored collection has another vector size")
-                else:
-                    col = _Collection(int(dense_vector_size), [int(m) for m in matryoshka_sizes], self.device)
-                    col.sparse_enabled = bool(sparse_enabled)
-                self._collections[user_id] = col
+                    self._drop(user_id, old)
+                self._collections[user_id] = self._open_collection(
+                    user_id, int(dense_vector_size), [int(m) for m in matryoshka_sizes], bool(sparse_enabled),
+                    bool(force_recreate))
             await self._run(make)
             logging.info("create_collection: new collection for %s", user_id)
         except ValueError as ve:
@@ -153,6 +151,22 @@ class QdrantHandler:
         except Exception as e:
             logging.critical(f"Collection creation failed for user {user_id}: {str(e)}")
             raise
+
+    # the two places a collection's engine index is made and dropped: sharded.ShardedHandler overrides them
+    def _open_collection(self, user_id, dim, msizes, sparse_enabled, force_recreate) -> _Collection:
+        base = self._base(user_id)
+        if base and not force_recreate and os.path.exists(base + ".hx") and os.path.exists(base + ".json"):
+            col = _Collection.load(base, self.device)
+            if col.dim != dim:
+                col.close()
+                raise ValueError("stored collection has another vector size")
+        else:
+            col = _Collection(dim, msizes, self.device)
+            col.sparse_enabled = sparse_enabled
+        return col
+
+    def _drop(self, user_id, col: _Collection) -> None:
+        col.close()
 
     def _base(self, user_id: str) -> Optional[str]:
         if not self.persist_dir:
@@ -251,7 +265,7 @@ class QdrantHandler:
             raise
 
     # ---------------------------------------------------------------------------- search
-    def _search_sync(self, user_id, dense_vectors, sparse_vectors, search_params, filters):
+    def _search_sync(self, user_id, dense_vectors, sparse_vectors, search_params, filters, mode="tree"):
         col = self._collections[str(user_id)]
         q = np.asarray(dense_vectors, dtype=np.float32).reshape(len(sparse_vectors), -1)
         if q.shape[1] != col.dim:
@@ -262,8 +276,13 @@ class QdrantHandler:
             idx.extend(int(i) for i in si)
             val.extend(float(v) for v in vv)
             indptr.append(len(idx))
-        hp = _engine.make_params(search_params, mode=HX_MODE_TREE)   # KeyError/TypeError like the reference
+        if mode not in ("tree", "h1"):
+            raise ValueError("mode must be 'tree' (the reference query) or 'h1'")
+        # KeyError/TypeError like the reference when search_params lacks a key / is None
+        hp = _engine.make_params(search_params, mode=HX_MODE_TREE if mode == "tree" else HX_MODE_H1)
         final_limit = int(hp.final_limit)
+        if filters and mode != "tree":
+            raise ValueError("filters belong to the reference query's root (:297, :371): use mode='tree'")
         if filters:
             # query_filter belongs to the ROOT query only (:297, :371): the union of the branches'
             # candidates (<= dense_limit + the fusion's 10) is re-scored, filtered, cut to final_limit.
@@ -301,10 +320,12 @@ class QdrantHandler:
 
     async def hybrid_search_batch(self, user_id: str, dense_vectors, sparse_vectors, top_k: int = 10,
                                   search_params: Optional[Dict[str, Any]] = None,
-                                  filters: Optional[Dict] = None) -> List[List[ScoredPoint]]:
-        """B queries in one engine call (additive; no reranking hook)."""
+                                  filters: Optional[Dict] = None, mode: str = "tree") -> List[List[ScoredPoint]]:
+        """B queries in one engine call (additive; no reranking hook).  mode "tree" = the reference query
+        (:305-372), "h1" = dense top-dense_limit (+) sparse top-sparse_limit -> RRF -> final_limit."""
         try:
-            res = await self._run(self._search_sync, user_id, dense_vectors, sparse_vectors, search_params, filters)
+            res = await self._run(self._search_sync, user_id, dense_vectors, sparse_vectors, search_params, filters,
+                                  mode)
             return [r[:top_k] for r in res]
         except Exception as e:
             logging.error("hybrid search for %s failed: %s", user_id, e)
@@ -335,7 +356,7 @@ class QdrantHandler:
         try:
             def drop():
                 col = self._collections.pop(str(user_id))   # KeyError if absent: re-raised
-                col.close()
+                self._drop(str(user_id), col)
             await self._run(drop)
             logging.info("delete_collection: %s dropped", user_id)
         except Exception as e:

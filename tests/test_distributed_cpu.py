@@ -206,22 +206,90 @@ def test_two_rank_sharded_tree_equals_unsharded_oracle():
 
 # ---------------------------------------------------------------------------- the sharded front end (C2 + ingest)
 class GrowingShard(FakeShard):
-    """engine.HxIndex stand-in that also ingests: an oracle index over this rank's rows, global ids = id_base + row"""
+    """engine.HxIndex stand-in that also ingests: an oracle index over this rank's rows; the global id of a local
+    row is what `set_next_id` named when its block arrived (hx_set_next_id), `truncate` rolls a block back
+    (hx_truncate).  `fail_adds` / `fail_searches`: the add / search_dense calls (by number) that raise, `hang`:
+    seconds the next search_dense sleeps -- a shard in trouble."""
+    fail_adds = ()
+    fail_searches = ()
+    hang = 0.0
 
     def __init__(self, dim, msizes, id_base):
         from oracle import oracle as O
         super().__init__(O.OracleIndex(dim, msizes), id_base)
+        self.gids = np.zeros(0, np.int64)
+        self.next = None
+        self.n_add = self.n_search = 0
+
+    def set_next_id(self, first):
+        assert self.gids.size == 0 or first > self.gids[-1]
+        self.next = int(first)
 
     def add(self, dense, ip=None, ix=None, v=None):
+        k, self.n_add = self.n_add, self.n_add + 1
+        first, self.next = self.next, None
+        if k in self.fail_adds:
+            raise RuntimeError("shard refuses the block")
+        n = len(dense)
+        first = first if first is not None else (int(self.gids[-1]) + 1 if self.gids.size else self.r0)
         self.ora.add(dense, ip, ix, v)
+        self.gids = np.concatenate([self.gids, first + np.arange(n, dtype=np.int64)])
+
+    def truncate(self, n):
+        o = self.ora
+        o.raw = o.raw[:n]
+        o.sp_idx, o.sp_val = o.sp_idx[:o.sp_indptr[n]], o.sp_val[:o.sp_indptr[n]]
+        o.sp_indptr = o.sp_indptr[:n + 1]
+        o._final = False
+        self.gids = self.gids[:n]
+
+    def count(self):
+        return self.ora.n
+
+    def _shift(self, s, i):
+        return s, self.gids[i]
+
+    def search_dense(self, q, limit, prefix=0):
+        k, self.n_search = self.n_search, self.n_search + 1
+        if k in self.fail_searches:
+            raise RuntimeError("shard cannot search")
+        if self.hang:
+            import time
+            time.sleep(self.hang)
+        return super().search_dense(q, limit, prefix)
+
+    def rescore(self, q, cand_keys, cand_counts, limit, prefix=0):
+        out = []
+        for b, x in enumerate(q.numpy()):
+            row = cand_keys[b].numpy()
+            if cand_counts is not None:
+                row = row[: int(cand_counts[b])]
+            g = unkey(row[row != 0])[1]
+            loc = np.searchsorted(self.gids, g)
+            loc = loc[(loc < self.gids.size) & (self.gids[np.minimum(loc, max(self.gids.size - 1, 0))] == g)] \
+                if self.gids.size else loc[:0]
+            out.append(self._shift(*self.ora.rescore(x, loc, limit, prefix)) if len(loc) else
+                       (np.zeros(0, np.float32), np.zeros(0, np.int64)))
+        return keys_of(out, limit)
+
+
+def _chunks(O, tabs, n, dim):
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
+    return [{"content": f"chunk {r}", "dense_embedding": X[r].tolist(),
+             "sparse_embedding": {"indices": si[ip[r]:ip[r + 1]].tolist(), "values": sv[ip[r]:ip[r + 1]].tolist()},
+             "chunk_metadata": {"document_id": f"d{r % 5}", "user_id": "u", "file_name": f"f{r % 3}.txt", "mime_type": "text/plain",
+                                "file_size": 1, "description": "", "file_path": "/p", "context_version": 1,
+                                "chunk_number": r, "doc_summary": "s"}} for r in range(n)]
 
 
 def front_worker(rank, world, port, n, dim, B, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import asyncio
+    import datetime
     from oracle import oracle as O
-    from rag_application_amd.sharded import ShardedCollection, ShardedHandler, bcast_queries
+    from rag_application_amd.sharded import ShardedCollection, ShardedHandler, ShardError, bcast_queries
     tabs = O.synth_tables()
     # -- C2 alone: the packed broadcast delivers the front rank's batch bit for bit
     Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
@@ -234,44 +302,86 @@ def front_worker(rank, world, port, n, dim, B, ret):
     assert np.array_equal(got[0].numpy(), Q) and np.array_equal(got[1].numpy(), qip)
     assert np.array_equal(got[2].numpy(), qsi.astype(np.int32)) and np.array_equal(got[3].numpy(), qsv)
     # -- the handler: rank 0 is the application, the others serve
-    h = ShardedHandler(index_factory=GrowingShard, ops=CpuOpsH1, dense_vector_size=dim)
+    shards = []
+
+    def factory(d, ms, base):
+        shards.append(GrowingShard(d, ms, base))
+        return shards[-1]
+
+    class Rerank:                                   # rerank hook (qdrant_handler.py:380): reverses the list
+        def rerank_documents(self, query, documents, max_tokens):
+            return list(range(len(documents)))[::-1]
+
+    h = ShardedHandler(index_factory=factory, ops=CpuOpsH1, dense_vector_size=dim, reranker=Rerank(), timeout=60)
     if rank != 0:
         h.serve()
     else:
-        X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
-        ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
-        chunks = [{"content": f"chunk {r}", "dense_embedding": X[r].tolist(),
-                   "sparse_embedding": {"indices": si[ip[r]:ip[r + 1]].tolist(), "values": sv[ip[r]:ip[r + 1]].tolist()},
-                   "chunk_metadata": {"document_id": "d", "user_id": "u", "file_name": f"f{r % 3}.txt", "chunk_number": r,
-                                      "doc_summary": "s", "description": ""}} for r in range(n)]
+        chunks = _chunks(O, tabs, n, dim)
         run = asyncio.run
         try:
             run(h.store_document_vectors([dict(chunks[0], dense_embedding=[0.0] * 7)], "u"))
             raise AssertionError("dimension mismatch must raise")
         except ValueError:
             pass
-        cut = n * 2 // 3 + 1                      # two batches: blocks of different sizes on every rank
-        run(h.store_document_vectors(chunks[:cut], "u"))
-        run(h.store_document_vectors(chunks[cut:], "u"))
+        bad = dict(chunks[0], sparse_embedding={"indices": [5, 5], "values": [1.0, 2.0]})
+        try:                                      # refused on the front rank: the ranks never hear of the batch
+            run(h.store_document_vectors([bad], "u"))
+            raise AssertionError("duplicate sparse index must raise")
+        except ValueError:
+            pass
+        c1, c2 = n // 2 + 1, n // 2 + n // 7 + 2  # three uneven batches: blocks of different sizes on every rank
+        run(h.store_document_vectors(chunks[:c1], "u"))
+        run(h.store_document_vectors(chunks[c1:c2], "u"))
+        run(h.store_document_vectors(chunks[c2:], "u"))
         assert run(h.get_collection_chunk_count("u")) == n and run(h.get_all_containers()) == ["u"]
+        assert run(h.get_collection_chunk_count("u", filters={"must": [{"key": "file_name", "match": {"value": "f1.txt"}}]})) \
+            == len([r for r in range(n) if r % 3 == 1])
         sp = [{"indices": qsi[qip[b]:qip[b + 1]].tolist()[::-1], "values": qsv[qip[b]:qip[b + 1]].tolist()[::-1]}
               for b in range(B)]                  # reversed term order: the front end sorts by term id
         tree = run(h.hybrid_search_batch("u", Q.tolist(), sp, top_k=12, search_params=P))
         h1 = run(h.hybrid_search_batch("u", Q.tolist(), sp, top_k=10, search_params=P, mode="h1"))
-        one = run(h.hybrid_search("u", "text", Q[0].tolist(), sp[0], top_k=3, search_params=P))
+        one = run(h.hybrid_search("u", "text", Q[0].tolist(), sp[0], top_k=3, search_params=P))   # rerank hook: reversed
         assert run(h.hybrid_search("u", "text", Q[0].tolist(), sp[0], search_params=None)) == []
-        ret["tree"] = [[(p.payload["chunk_number"], p.score, p.payload["content"]) for p in row] for row in tree]
+        flt = {"must": [{"key": "file_name", "match": {"value": "f1.txt"}}]}
+        filt = run(h.hybrid_search_batch("u", Q.tolist(), sp, top_k=12, search_params=P, filters=flt))
+        ret["tree"] = [[(p.payload["chunk_number"], p.score, p.payload["content"], sorted(p.payload)) for p in row] for row in tree]
         ret["h1"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in h1]
         ret["one"] = [(p.payload["chunk_number"], p.score) for p in one]
-        # a second collection ingested as ONE batch: engine row ids are then in insertion order on every rank, so
-        # even the ties of the RRF scores break as in the unsharded oracle
-        run(h.store_document_vectors(chunks, "v"))
-        h1v = run(h.hybrid_search_batch("v", Q.tolist(), sp, top_k=10, search_params=P, mode="h1"))
-        ret["h1v"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in h1v]
-        run(h.delete_collection("v"))
+        ret["filt"] = [[(p.payload["chunk_number"], p.score, p.payload["file_name"]) for p in row] for row in filt]
+        # chat vectors (qdrant_handler.py:200-267) into a collection of their own
+        chats = [{"dense_embedding": c["dense_embedding"], "sparse_embedding": c["sparse_embedding"], "chat_id": f"c{r}",
+                  "message_type": "user", "timestamp": "2025-01-01T00:00:00", "entities": [], "relationships": [],
+                  "chat_summary": "", "message": f"msg {r}"} for r, c in enumerate(chunks[:40])]
+        run(h.store_chat_vectors(chats[:13], "chat"))
+        run(h.store_chat_vectors(chats[13:], "chat"))
+        ch = run(h.hybrid_search_batch("chat", Q[:2].tolist(), sp[:2], top_k=5, search_params=P))
+        ret["chat"] = [[(p.payload["content"], p.payload["is_chat"], p.score) for p in row] for row in ch]
+        # -- a shard that fails: store rolls back everywhere and raises; search returns []
+        run(h.create_collection("w", dense_vector_size=dim))
+        run(h.store_document_vectors(chunks[:50], "w"))
+        try:
+            run(h.store_document_vectors(chunks[50:90], "w"))      # the worker's shard refuses its block (its 2nd add)
+            raise AssertionError("a failed shard must make the store raise")
+        except ShardError as e:
+            assert "rank 1" in str(e)
+        assert run(h.get_collection_chunk_count("w")) == 50 and shards[-1].count() == 25   # this rank rolled back
+        run(h.store_document_vectors(chunks[50:90], "w"))          # ... and the same batch goes in afterwards
+        hw = run(h.hybrid_search_batch("w", Q.tolist(), sp, top_k=10, search_params=P, mode="h1"))
+        ret["h1w"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in hw]
+        assert run(h.hybrid_search("w", "text", Q[0].tolist(), sp[0], search_params=P)) == []   # worker's search raises
+        assert len(run(h.hybrid_search("w", "text", Q[0].tolist(), sp[0], search_params=P))) == 10   # ... once
+        try:
+            run(h.delete_collection("nobody"))
+            raise AssertionError("unknown collection must raise")
+        except KeyError:
+            pass
+        run(h.delete_collection("w"))
+        run(h.delete_collection("chat"))
         run(h.delete_collection("u"))
         assert run(h.get_collection_chunk_count("u")) == 0
         h.shutdown()
+    if rank == 1:                                   # the failures the front rank met above were planned here
+        pass
     # -- ingest of TEXT chunks with a per-rank encoder replica (BASELINE config 5's shape): every rank encodes its block
     class Enc:
         def encode(self, texts):
@@ -279,23 +389,41 @@ def front_worker(rank, world, port, n, dim, B, ret):
                 np.zeros((0, dim), np.float32)
     col = ShardedCollection(dim, (64, 128, 256), index_factory=GrowingShard, ops=CpuOpsH1)
     texts = [f"row {r}" for r in range(101)]
-    seq = col.store(texts=texts if rank == 0 else None, encoder=Enc())
+    seq = col.store(texts=texts[:40] if rank == 0 else None, encoder=Enc())
+    seq2 = col.store(texts=texts[40:] if rank == 0 else None, encoder=Enc())
     assert col.count() == 101 and col.counts.tolist() == [50, 51]
     k, c = col.search(*((Q[:2], np.zeros(3, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32),
                          dict(P, sparse_limit=5), "h1") if rank == 0 else (None,) * 6))
     if rank == 0:
-        assert seq.tolist() == list(range(101))
+        assert seq.tolist() == list(range(40)) and seq2.tolist() == list(range(40, 101))
         ret["texts"] = col.resolve(k, c)
     dist.barrier()
     dist.destroy_process_group()
 
 
+# the worker rank's planned failures: collection "w" is the third one its handler opens ("u", "chat", "w")
+_orig_init = GrowingShard.__init__
+
+
+def _planned_init(self, dim, msizes, id_base):
+    _orig_init(self, dim, msizes, id_base)
+    GrowingShard._made = getattr(GrowingShard, "_made", 0) + 1
+    if dist.is_initialized() and dist.get_rank() == 1 and GrowingShard._made == 3:
+        self.fail_adds = (1,)          # its second block
+        self.fail_searches = (1,)      # one search_dense call per query batch: the batch after the H1 batch
+
+
+GrowingShard.__init__ = _planned_init
+
+
 @pytest.mark.timeout(600)
 def test_sharded_front_end_from_rank0_equals_unsharded_oracle():
-    """ShardedHandler on two ranks (gloo): rank 0 ingests two batches (dealt in contiguous blocks, row counts
-    all-gathered) and queries (ONE packed broadcast per batch); rank 1 serves.  Payloads, ids and score bits of
-    the reference tree and of H1 equal the oracle on the unsharded corpus in insertion order."""
+    """ShardedHandler on two ranks (gloo): rank 0 ingests THREE uneven batches (dealt in contiguous blocks, ids named
+    per block) and queries (ONE packed broadcast per batch); rank 1 serves.  Payloads, ids and score bits of the
+    reference tree and of H1 equal the oracle on the unsharded corpus in insertion order -- ties included.  Chat
+    vectors, a payload filter, the rerank hook, and a shard that fails (store rolls back + raises, search -> [])."""
     from oracle import oracle as O
+    from rag_application_amd import filters as F
     n, dim, B, world = 900, 256, 4, 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -306,30 +434,97 @@ def test_sharded_front_end_from_rank0_equals_unsharded_oracle():
     tabs = O.synth_tables()
     full = O.OracleIndex(dim, (64, 128, 256))
     ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
-    full.add(O.synth_dense(O.SEED_CORPUS, 0, n, dim), ip, si, sv)
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    full.add(X, ip, si, sv)
     full.finalize()
     Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
     qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, tabs)
+    REF_PAYLOAD = sorted(["document_id", "user_id", "file_name", "mime_type", "file_size", "file_description", "file_path",
+                          "context_version", "chunk_number", "entities", "relationships", "context", "document_summary",
+                          "content", "page_number", "languages", "element_id", "is_continuation", "category"])
     for b in range(B):
         sp = (qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]])
         es, ei = O.hybrid_tree(full, Q[b], *sp, P)
         assert [t[0] for t in ret["tree"][b]] == ei.tolist() and [t[2] for t in ret["tree"][b]] == [f"chunk {i}" for i in ei]
+        assert all(t[3] == REF_PAYLOAD for t in ret["tree"][b])         # the reference's 19 fields (qdrant_handler.py:165-185)
         np.testing.assert_array_equal(np.array([t[1] for t in ret["tree"][b]], np.float32).view(np.uint32), es.view(np.uint32))
+        # H1 over three batches: ids AND score bits, no carve-out for ties
         es, ei = O.hybrid_h1(full, Q[b], *sp, P["dense_limit"], P["sparse_limit"], P["final_limit"])
-        assert [t[0] for t in ret["h1v"][b]] == ei[:10].tolist()
-        np.testing.assert_array_equal(np.array([t[1] for t in ret["h1v"][b]], np.float32).view(np.uint32), es[:10].view(np.uint32))
-        # two batches: rank r's rows of batch 2 precede rank r + 1's rows of batch 1 in engine id order, so equal
-        # RRF scores may break differently from insertion order -- the scores, and the ids outside tie groups, agree
-        got_s = np.array([t[1] for t in ret["h1"][b]], np.float32)
-        np.testing.assert_array_equal(got_s.view(np.uint32), es[:10].view(np.uint32))
-        for k in range(10):
-            if (es[:10] == es[k]).sum() == 1 and (k == 9 or es[k] != es[min(k + 1, len(es) - 1)]):
-                assert ret["h1"][b][k][0] == int(ei[k])
+        assert [t[0] for t in ret["h1"][b]] == ei[:10].tolist()
+        np.testing.assert_array_equal(np.array([t[1] for t in ret["h1"][b]], np.float32).view(np.uint32), es[:10].view(np.uint32))
+        # the filter belongs to the root query (:297, :371): the re-scored union, filtered, cut to final_limit
+        us, ui = O.hybrid_tree(full, Q[b], *sp, dict(P, final_limit=P["dense_limit"] + 10))
+        keep = [(int(i), s) for s, i in zip(us, ui) if i % 3 == 1][:P["final_limit"]]
+        assert [t[0] for t in ret["filt"][b]] == [k[0] for k in keep] and all(t[2] == "f1.txt" for t in ret["filt"][b])
     es, ei = O.hybrid_tree(full, Q[0], qsi[qip[0]:qip[1]], qsv[qip[0]:qip[1]], P)
-    assert [t[0] for t in ret["one"]] == ei[:3].tolist()
+    assert [t[0] for t in ret["one"]] == ei[::-1][:3].tolist()          # the rerank hook reversed the list, then [:top_k]
+    # chat vectors: 40 rows in two batches, the chat payload
+    chat = O.OracleIndex(dim, (64, 128, 256))
+    chat.add(X[:40], ip[:41], si[:ip[40]], sv[:ip[40]])
+    for b in range(2):
+        es, ei = O.hybrid_tree(chat, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], P)
+        assert [t[0] for t in ret["chat"][b]] == [f"msg {i}" for i in ei[:5]] and all(t[1] is True for t in ret["chat"][b])
+    # collection "w": the batch that failed once is in exactly once
+    w = O.OracleIndex(dim, (64, 128, 256))
+    w.add(X[:90], ip[:91], si[:ip[90]], sv[:ip[90]])
+    for b in range(B):
+        es, ei = O.hybrid_h1(w, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], P["dense_limit"], P["sparse_limit"], P["final_limit"])
+        assert [t[0] for t in ret["h1w"][b]] == ei[:10].tolist()
     # the text ingest: row r was encoded (on whichever rank got it) as synth_dense(900, r): dense-only H1
     enc = O.OracleIndex(dim, (64, 128, 256))
     enc.add(np.stack([O.synth_dense(900, r, 1, dim)[0] for r in range(101)]))
     for b in range(2):
         es, ei = O.rrf([enc.search_dense(Q[b], P["dense_limit"])[1], np.zeros(0, np.int64)], limit=P["final_limit"])
         assert [t[0] for t in ret["texts"][b]] == ei.tolist()
+
+
+def hang_worker(rank, world, port, dim, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import asyncio
+    import time
+    from oracle import oracle as O
+    from rag_application_amd.sharded import ShardedHandler, ShardError
+    tabs = O.synth_tables()
+    shards = []
+
+    def factory(d, ms, base):
+        shards.append(GrowingShard(d, ms, base))
+        if rank == 1:
+            shards[-1].hang = 12.0             # the worker's shard stops answering
+        return shards[-1]
+
+    h = ShardedHandler(index_factory=factory, ops=CpuOpsH1, dense_vector_size=dim, timeout=3)
+    if rank != 0:
+        h.serve()                              # ends when the group is found broken
+    else:
+        run = asyncio.run
+        chunks = _chunks(O, tabs, 60, dim)
+        run(h.store_document_vectors(chunks, "u"))
+        Q = O.synth_dense(O.SEED_QUERY, 0, 1, dim)
+        t0 = time.time()
+        out = run(h.hybrid_search("u", "t", Q[0].tolist(), {"indices": [1], "values": [1.0]}, search_params=P))
+        ret["search"] = (out, time.time() - t0)
+        t0 = time.time()
+        try:
+            run(h.store_document_vectors(chunks, "u"))
+            ret["store"] = "stored"
+        except ShardError as e:
+            ret["store"] = ("raised", time.time() - t0)
+    # no barrier: the group is broken by design; each rank leaves on its own
+    time.sleep(1.0)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_handler_times_out_on_a_hanging_rank():
+    """A worker whose shard stops answering: the front rank's search returns [] and its next mutation raises, both
+    within the handler's timeout -- it is never left inside a collective (qdrant_handler.py:384-386, :196-198)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(hang_worker, args=(2, port, 128, ret), nprocs=2, join=True)
+    out, dt = ret["search"]
+    assert out == [] and dt < 10.0
+    assert ret["store"][0] == "raised" and ret["store"][1] < 10.0

@@ -1083,3 +1083,213 @@ def test_extremes(eng, torch_mod, n, dim, B, L, i8):
         for b in range(B):
             assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"i8 n={n} dim={dim} b={b}")
         ix8.close()
+
+
+# ---- insertion-order ids under row sharding (hx_set_next_id), rollback (hx_truncate), all-or-nothing device ingest --------
+def _interleaved_shards(eng, X, ip, si, sv, cuts, dim, msizes, world=2):
+    """`world` shards on one GPU holding the collection the way sharded.ShardedCollection.store deals it: every batch
+    [cuts[k], cuts[k+1]) is cut into contiguous blocks, shard r takes block r and names its first id."""
+    shards = [eng.HxIndex(dim, msizes) for _ in range(world)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        n = b - a
+        for r in range(world):
+            r0, r1 = a + n * r // world, a + n * (r + 1) // world
+            if r1 == r0:
+                continue
+            shards[r].set_next_id(r0)
+            shards[r].add(X[r0:r1], ip[r0:r1 + 1] - ip[r0], si[ip[r0]:ip[r1]].astype(np.int32), sv[ip[r0]:ip[r1]])
+    return shards
+
+
+def test_insertion_order_ids_three_batches_two_shards(eng, torch_mod, synth_tables, tmp_path):
+    """A collection ingested in THREE uneven batches over two shards (each holds a slice of every batch, ids named
+    per block with hx_set_next_id): every stage's keys carry insertion-order ids, so the merged lists -- tree and H1,
+    ties included -- equal the oracle on the unsharded collection key for key.  The same after save + load."""
+    n, dim, B = 7000, 256, 9
+    tabs = synth_tables
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    X[3500:3540] = X[100:140]                     # duplicate rows in another batch AND another shard: dense ties
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
+    ora = O.OracleIndex(dim, (64, 128))
+    ora.add(X, ip, si, sv)
+    ora.finalize()
+    cuts = [0, 2501, 2502 + 1777, n]
+    shards = _interleaved_shards(eng, X, ip, si, sv, cuts, dim, (64, 128))
+    assert sum(s.count() for s in shards) == n
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    Q[0] = X[105]                                 # its best rows tie exactly (rows 105 and 3505, on different shards)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, tabs)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(),
+          torch_mod.from_numpy(qsv).cuda())
+    P = dict(matryoshka_64_limit=80, matryoshka_128_limit=50, dense_limit=30, quantized_limit=35, sparse_limit=25,
+             final_limit=12, hnsw_ef=1)
+
+    def glob(parts, limit, dedupe=False):
+        return eng.merge(torch_mod.cat([k for k, _ in parts], dim=1), None, limit, dedupe)
+
+    def run(shards, what):
+        c = glob([s.search_dense(Qd, 80, 64) for s in shards], 80)
+        c = glob([s.rescore(Qd, c[0], c[1], 50, 128) for s in shards], 50)
+        a = glob([s.rescore(Qd, c[0], c[1], 30, 0) for s in shards], 30)
+        q8 = glob([s.search_i8(Qd, 35) for s in shards], 35)
+        dq = glob([s.rescore(Qd, q8[0], q8[1], 30, 0) for s in shards], 30)
+        sp = glob([s.search_sparse(*tq, 25) for s in shards], 25)
+        r = eng.rrf(dq[0], dq[1], sp[0], sp[1], limit=10)
+        u = torch_mod.cat([a[0], r[0]], dim=1)
+        out = glob([s.rescore(Qd, u, None, 12, 0) for s in shards], 12)
+        s_, i_, c_ = unpack_np(eng, *out)
+        for b in range(B):
+            es, ei = O.hybrid_tree(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], P)
+            assert_list_equal(s_[b], i_[b], c_[b], es, ei, f"{what}: tree b={b}")
+        d = glob([s.search_dense(Qd, 40) for s in shards], 40)
+        s_, i_, c_ = unpack_np(eng, *d)
+        for b in range(B):
+            es, ei = ora.search_dense(Q[b], 40)
+            assert_list_equal(s_[b], i_[b], c_[b], es, ei, f"{what}: dense b={b}")
+        allk = torch_mod.cat([s.h1_local(Qd, *tq, 40, 25) for s in shards], dim=0)
+        s_, i_, c_ = unpack_np(eng, *eng.h1_fuse(allk, len(shards), 40, 25, limit=10))
+        alla = torch_mod.cat([s.h1_local_async(Qd, *tq, 40, 25)[:B] for s in shards], dim=0)
+        assert torch_mod.equal(alla, allk)
+        for b in range(B):
+            es, ei = O.hybrid_h1(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], 40, 25, 10)
+            assert_list_equal(s_[b], i_[b], c_[b], es, ei, f"{what}: h1 b={b}")
+
+    run(shards, "three batches")
+    assert 105 in unpack_np(eng, *glob([s.search_dense(Qd[:1], 2) for s in shards], 2))[1][0] \
+        and 3505 in unpack_np(eng, *glob([s.search_dense(Qd[:1], 2) for s in shards], 2))[1][0]
+    # ids must ascend with a shard's rows; the whole tree through one shard alone carries global ids too
+    with pytest.raises(eng.HxError, match="ascend"):
+        shards[0].set_next_id(5)
+    hp = eng.make_params(dict(P, matryoshka_256_limit=1), mode=eng.HX_MODE_TREE)
+    k0, c0 = shards[0].hybrid_query(Qd, *tq, hp)
+    ids0 = unpack_np(eng, k0, c0)[1]
+    mine = np.concatenate([np.arange(a + (b - a) * 0 // 2, a + (b - a) * 1 // 2) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.isin(ids0[ids0 >= 0], mine).all()
+    # save + load keeps the block table
+    loaded = []
+    for r, s in enumerate(shards):
+        path = str(tmp_path / f"s{r}.hx")
+        s.save(path)
+        loaded.append(eng.HxIndex.load(path))
+    run(loaded, "loaded")
+    for s in shards + loaded:
+        s.close()
+
+
+def test_truncate_rolls_a_batch_back(eng, torch_mod, synth_tables, monkeypatch):
+    """hx_truncate: an index that stored a batch and rolled it back answers like one that never saw it -- dense,
+    int8 and sparse (base and tail of the inverted index), and takes the next batch (with its ids) as if nothing
+    had happened."""
+    monkeypatch.setenv("HX_DEBUG_TAIL_MIN", "100000")         # keep a tail index in play
+    n, dim, B = 6000, 128, 6
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    Q = torch_mod.from_numpy(O.synth_dense(O.SEED_QUERY, 0, B, dim)).cuda()
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
+
+    def blk(a, b):
+        return X[a:b], ip[a:b + 1] - ip[a], si[ip[a]:ip[b]].astype(np.int32), sv[ip[a]:ip[b]]
+
+    def lists(ix):
+        return [ix.search_dense(Q, 20), ix.search_i8(Q, 20), ix.search_sparse(*tq, 30), ix.search_dense(Q, 25, 64)]
+
+    ref = eng.HxIndex(dim, (64,))
+    ref.add(*blk(0, 3000))
+    ix = eng.HxIndex(dim, (64,))
+    ix.add(*blk(0, 3000))
+    base = lists(ix)                               # builds the inverted index (base)
+    ix.set_next_id(9000)
+    ix.add(*blk(3000, 4500))
+    lists(ix)                                      # ... and a tail over the new rows
+    ix.truncate(3000)
+    assert ix.count() == 3000 and ix.stats()["nnz"] == ip[3000]
+    for (k0, c0), (k1, c1), (k2, c2) in zip(base, lists(ix), lists(ref)):
+        assert torch_mod.equal(k0, k1) and torch_mod.equal(c0, c1) and torch_mod.equal(k1, k2)
+    # cut below the base of the inverted index
+    ix.truncate(1000)
+    ref2 = eng.HxIndex(dim, (64,))
+    ref2.add(*blk(0, 1000))
+    for (k1, c1), (k2, c2) in zip(lists(ix), lists(ref2)):
+        assert torch_mod.equal(k1, k2) and torch_mod.equal(c1, c2)
+    # the index keeps growing: a block with named ids
+    for i in (ix, ref2):
+        i.set_next_id(5000)
+        i.add(*blk(1000, 1700))
+    for (k1, c1), (k2, c2) in zip(lists(ix), lists(ref2)):
+        assert torch_mod.equal(k1, k2) and torch_mod.equal(c1, c2)
+    got = unpack_np(eng, *ix.search_dense(Q, 20))[1]
+    assert ((got < 1000) | ((got >= 5000) & (got < 5700))).all()
+    with pytest.raises(eng.HxError):
+        ix.truncate(ix.count() + 1)
+    for i in (ix, ref, ref2):
+        i.close()
+
+
+def test_device_ingest_is_all_or_nothing(eng, torch_mod):
+    """hx_add_rows_dev: a batch whose sparse half is refused stores nothing (count, nnz and the next batch's ids
+    are as before) -- what hx_add_rows guarantees for host rows."""
+    ix = eng.HxIndex(64, ())
+    Xd = torch_mod.from_numpy(O.synth_dense(7, 0, 4, 64)).cuda()
+    ip = np.asarray([0, 1, 2, 2, 3], np.int64)
+    ix.add_device(Xd, ip, np.asarray([1, 2, 3], np.int32), np.asarray([1.0, 0.5, 2.0], np.float32))
+    for bad_idx, bad_val, pat in ((np.asarray([5, 5, 1], np.int32), np.ones(3, np.float32), "unique"),
+                                  (np.asarray([1, 2, 3], np.int32), np.asarray([1.0, np.inf, 1.0], np.float32), "finite")):
+        ix.set_next_id(100)
+        with pytest.raises(eng.HxError, match=pat):
+            ix.add_device(Xd, np.asarray([0, 2, 2, 2, 3], np.int64), bad_idx, bad_val)
+        assert ix.count() == 4 and ix.stats()["nnz"] == 3
+    ix.add_device(Xd, ip, np.asarray([1, 2, 3], np.int32), np.asarray([1.0, 0.5, 2.0], np.float32))   # ids 4..7: the refused
+    assert ix.count() == 8 and ix.stats()["nnz"] == 6                                                 # call consumed its id
+    ids = unpack_np(eng, *ix.search_dense(Xd, 8))[1]
+    assert sorted(ids[0].tolist()) == list(range(8))
+    ix.close()
+
+
+def test_unsorted_sparse_query_is_refused(eng, torch_mod, synth_tables):
+    """The device entries take query term ids strictly ascending (the exact score is a running fp32 sum in that
+    order): k_sparse_prep checks it, and a batch with a reversed or repeated query fails instead of returning other
+    score bits -- through hx_search_sparse, hx_h1_local, and as a flagged batch through hx_h1_local_async."""
+    n, dim = 3000, 64
+    ora, ix, X = build_pair(eng, n, dim, (), synth_tables)
+    Q = torch_mod.from_numpy(O.synth_dense(O.SEED_QUERY, 0, 3, dim)).cuda()
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, 3, synth_tables)
+    good = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
+    ix.search_sparse(*good, 10)
+    rev = qsi.copy().astype(np.int32)
+    rev[qip[1]:qip[2]] = rev[qip[1]:qip[2]][::-1]
+    assert qip[2] - qip[1] >= 2
+    dup = qsi.copy().astype(np.int32)
+    dup[qip[1] + 1] = dup[qip[1]]
+    for bad in (rev, dup):
+        tq = (good[0], torch_mod.from_numpy(bad).cuda(), good[2])
+        with pytest.raises(eng.HxError, match="ascending"):
+            ix.search_sparse(*tq, 10)
+        with pytest.raises(eng.HxError, match="ascending"):
+            ix.h1_local(Q, *tq, 10, 10)
+        flag = ix.h1_local_async(Q, *tq, 10, 10)[3, 0]
+        assert int(flag) != 0
+    ix.close()
+
+
+def test_load_refuses_a_repeated_term_id(eng, torch_mod, synth_tables, tmp_path):
+    """hx_load checks what hx_add_sparse enforces: a file whose CSR repeats a term id inside a row is refused."""
+    n, dim = 500, 64
+    ora, ix, X = build_pair(eng, n, dim, (), synth_tables)
+    path = str(tmp_path / "c.hx")
+    ix.save(path)
+    eng.HxIndex.load(path).close()
+    blob = bytearray(open(path, "rb").read())
+    nnz = ix.stats()["nnz"]
+    off = len(blob) - nnz * 8                      # [.. | sp_idx int32 x nnz | sp_val f32 x nnz]
+    idx = np.frombuffer(bytes(blob[off:off + nnz * 4]), np.int32).copy()
+    ip, _, _ = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    r = int(np.argmax(np.diff(ip) >= 2))
+    idx[ip[r] + 1] = idx[ip[r]]
+    blob[off:off + nnz * 4] = idx.tobytes()
+    bad = str(tmp_path / "bad.hx")
+    open(bad, "wb").write(bytes(blob))
+    with pytest.raises(eng.HxError, match="repeats"):
+        eng.HxIndex.load(bad)
+    ix.close()
