@@ -246,6 +246,19 @@ class GrowingShard(FakeShard):
     def count(self):
         return self.ora.n
 
+    def save(self, path):
+        o = self.ora
+        np.savez(path + ".npz", raw=o.raw, ip=o.sp_indptr, ix=o.sp_idx, v=o.sp_val, gids=self.gids,
+                 msizes=np.asarray(o.msizes))
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path + ".npz")
+        self = cls(z["raw"].shape[1], tuple(int(m) for m in z["msizes"]), 0)
+        self.ora.add(z["raw"], z["ip"], z["ix"], z["v"])
+        self.gids = z["gids"]
+        return self
+
     def _shift(self, s, i):
         return s, self.gids[i]
 
@@ -312,7 +325,11 @@ def front_worker(rank, world, port, n, dim, B, ret):
         def rerank_documents(self, query, documents, max_tokens):
             return list(range(len(documents)))[::-1]
 
-    h = ShardedHandler(index_factory=factory, ops=CpuOpsH1, dense_vector_size=dim, reranker=Rerank(), timeout=60)
+    import tempfile
+    pdir = [tempfile.mkdtemp() if rank == 0 else None]
+    dist.broadcast_object_list(pdir, 0)
+    h = ShardedHandler(index_factory=factory, ops=CpuOpsH1, dense_vector_size=dim, reranker=Rerank(), timeout=60,
+                       persist_dir=pdir[0], index_loader=GrowingShard.load)
     if rank != 0:
         h.serve()
     else:
@@ -348,6 +365,15 @@ def front_worker(rank, world, port, n, dim, B, ret):
         ret["h1"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in h1]
         ret["one"] = [(p.payload["chunk_number"], p.score) for p in one]
         ret["filt"] = [[(p.payload["chunk_number"], p.score, p.payload["file_name"]) for p in row] for row in filt]
+        # persist_dir: every rank writes its shard, the front rank the ids + payloads; a dropped collection comes back
+        run(h.save_collection("u"))
+        run(h.delete_collection("u"))
+        assert run(h.get_collection_chunk_count("u")) == 0
+        run(h.create_collection("u"))
+        assert run(h.get_collection_chunk_count("u")) == n
+        again = run(h.hybrid_search_batch("u", Q.tolist(), sp, top_k=12, search_params=P))
+        assert [[(p.id, p.score, p.payload["content"]) for p in row] for row in again] == \
+            [[(p.id, p.score, p.payload["content"]) for p in row] for row in tree]
         # chat vectors (qdrant_handler.py:200-267) into a collection of their own
         chats = [{"dense_embedding": c["dense_embedding"], "sparse_embedding": c["sparse_embedding"], "chat_id": f"c{r}",
                   "message_type": "user", "timestamp": "2025-01-01T00:00:00", "entities": [], "relationships": [],
@@ -401,14 +427,14 @@ def front_worker(rank, world, port, n, dim, B, ret):
     dist.destroy_process_group()
 
 
-# the worker rank's planned failures: collection "w" is the third one its handler opens ("u", "chat", "w")
+# the worker rank's planned failures: collection "w" is the fourth shard it makes ("u", "u" loaded again, "chat", "w")
 _orig_init = GrowingShard.__init__
 
 
 def _planned_init(self, dim, msizes, id_base):
     _orig_init(self, dim, msizes, id_base)
     GrowingShard._made = getattr(GrowingShard, "_made", 0) + 1
-    if dist.is_initialized() and dist.get_rank() == 1 and GrowingShard._made == 3:
+    if dist.is_initialized() and dist.get_rank() == 1 and GrowingShard._made == 4:
         self.fail_adds = (1,)          # its second block
         self.fail_searches = (1,)      # one search_dense call per query batch: the batch after the H1 batch
 
