@@ -244,19 +244,30 @@ typedef struct hx_stats {
   int64_t i8_fallback_queries;
   int64_t retry_queries;            /* queries re-run with the safe geometry (overflow, underflow, certificate) */
   int64_t sparse_fallback_queries;  /* sparse queries served document-at-a-time (non-positive weights, > 64 terms, overflow) */
+  /* ABI 2: the dense stage's candidate pass on the int8 matrix pipe (a per-row-scaled int8 copy of the normalised rows;
+   * final scores stay exact fp32).  Queries it took, queries whose certificate failed (re-run through the fp16 scan). */
+  int64_t bytes_i8_cand;
+  int64_t cand8_queries;
+  int64_t cand8_uncertified_queries;
+  double  cand8_row_error_max;      /* largest ||x - scale * x8||_2 of any stored row: what the certificate is built from */
 } hx_stats;
 int hx_get_stats(hx_index* h, hx_stats* out);
 /* HIP-event profile of the hot kernels, measured on the stream they run on.
- * Index 0 = fp16 scan (k_scan<F16>), 1 = int8 scan (k_scan<I8>), 2 = sparse scoring
+ * Index 0 = fp16 scan (k_scan<F16>), 1 = int8 scan of the "quantized" stage (k_scan<I8>), 3 = int8 candidate scan of
+ * the dense stage (the same kernel over the per-row-scaled copy), 2 = sparse scoring
  * (k_sparse_select: the pass over the inverted index; bytes = 8 per posting of the queries' terms).  flops/bytes are ALGORITHMIC: 2*B*rows*D and rows*row_bytes +
  * B*row_bytes per scan launch.  hx_profile_read drains what was recorded
  * since the last read (it synchronises the recorded events). */
 typedef struct hx_prof {
-  int64_t launches[3];
-  double ms[3];
-  double flops[3];
-  double bytes[3];
+  int64_t launches[4];
+  double ms[4];
+  double flops[4];
+  double bytes[4];
 } hx_prof;
+/* Which copy nominates the candidates of the full-vector dense stage: 1 = the per-row-scaled int8 copy (the
+ * default; a query its certificate does not cover is re-run on the fp16 copy), 0 = the fp16 copy.  The lists are the
+ * same either way (final scores are exact fp32): this is a measurement and test switch. */
+int hx_set_dense_candidates(hx_index* h, int32_t kind);
 int hx_profile(hx_index* h, int32_t enable);
 int hx_profile_read(hx_index* h, hx_prof* out);
 /* copy the derived row `row` (local) of one named vector to the host:

@@ -37,12 +37,13 @@ class HxStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_rows", "nnz", "n_segments", "n_groups", "hash_capacity", "bytes_dense_f32",
         "bytes_dense_f16", "bytes_i8", "bytes_prefix", "bytes_sparse",
-        "dense_fallback_queries", "i8_fallback_queries", "retry_queries", "sparse_fallback_queries")]
+        "dense_fallback_queries", "i8_fallback_queries", "retry_queries", "sparse_fallback_queries",
+        "bytes_i8_cand", "cand8_queries", "cand8_uncertified_queries")] + [("cand8_row_error_max", C.c_double)]
 
 
 class HxProf(C.Structure):
-    _fields_ = [("launches", C.c_int64 * 3), ("ms", C.c_double * 3), ("flops", C.c_double * 3),
-                ("bytes", C.c_double * 3)]
+    _fields_ = [("launches", C.c_int64 * 4), ("ms", C.c_double * 4), ("flops", C.c_double * 4),
+                ("bytes", C.c_double * 4)]
 
 
 _P = C.c_void_p
@@ -82,6 +83,7 @@ _SIGS = {
     "hx_load": [C.c_char_p, C.c_int32, C.POINTER(_P)],
     "hx_get_stats": [_P, C.POINTER(HxStats)],
     "hx_debug_row": [_P, C.c_int32, C.c_int64, _P],
+    "hx_set_dense_candidates": [_P, C.c_int32],
     "hx_profile": [_P, C.c_int32],
     "hx_profile_read": [_P, C.POINTER(HxProf)],
 }

@@ -92,7 +92,7 @@ enum WsSlot {
   WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC,
   WS_SP_TI0, WS_SP_TI1, WS_SP_QS, WS_SP_MARGIN, WS_SP_FLAG, WS_SP_WORK, WS_SP_FAIL, WS_SP_LIST, WS_SP_LCNT,
   WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF, WS_SP_QPARTS, WS_SP_SUM,
-  WS_ID_IN, WS_LONG_ROWS
+  WS_ID_IN, WS_LONG_ROWS, WS_Q8S, WS_SQ, WS_EPSQ
 };
 
 template <typename T>
@@ -121,6 +121,15 @@ struct hx_index {
   float* q8_rinv = nullptr;
   float* pre[3] = {nullptr, nullptr, nullptr};
   _Float16* pre_h0 = nullptr;
+  // Candidate-pass copy of the normalised rows (DESIGN.md "int8 candidate pass"): rint(x * 127 / max|x|), the
+  // row's scale, and -- one device word -- the largest quantisation error ||x - scale * x8|| of any row so far
+  // (fp32 bits, rounded up; a rollback leaves it as it is: an upper bound is all the certificate needs).
+  int8_t* q8s = nullptr;
+  float* q8s_scale = nullptr;
+  uint32_t* s8_err = nullptr;
+  int cand8 = 1;                      // 0: fp16 candidates only, no int8 copy is kept (HX_DENSE_CAND=f16)
+  bool cand8_off = false;             // hx_set_dense_candidates(h, 0): the copy is kept but the fp16 scan nominates
+  int64_t cand8_queries = 0, cand8_failed = 0;   // queries the int8 candidate pass took / could not certify
   // doc-major sparse staging (device)
   int64_t* sp_indptr = nullptr;  // [sp_rows_cap + 1]
   int32_t* sp_idx = nullptr;
@@ -146,8 +155,12 @@ struct hx_index {
   int64_t sparse_fallbacks = 0;       // queries served by the document-at-a-time path
   Workspace ws;
   int64_t dense_fallbacks = 0, i8_fallbacks = 0, retries = 0;
-  float* q8_tile_max = nullptr;     // max of q8_rinv per 256-row tile: the int8 scan's column bound
-  int64_t q8_tile_max_rows = -1, q8_tile_max_cap = 0;
+  // max of a per-row scale over every 256-row tile: the int8 scans' column bound (scan8.hip)
+  struct TileMax {
+    float* v = nullptr;
+    int64_t rows = -1, cap = 0;
+  };
+  TileMax tm_q8, tm_q8s;            // of q8_rinv (the "quantized" stage) and of q8s_scale (the candidate pass)
   int scan_logcap = SCAN8_LOGCAP;   // entries per wave log (HX_DEBUG_SCAN8_LOGCAP shrinks it: tests)
   // optional HIP-event profile of the scan / sparse kernels (hx_profile)
   struct ProfRec { hipEvent_t a, b; int what; double flops, bytes; };
@@ -199,6 +212,14 @@ static void reserve_rows(hx_index* h, int64_t want) {
   grow_copy(h->dense_h, n * h->dim_pad, nc * h->dim_pad, false);
   grow_copy(h->q8, n * h->dim_pad8, nc * h->dim_pad8, false);
   grow_copy(h->q8_rinv, n, nc + 256, true);
+  if (h->cand8) {
+    grow_copy(h->q8s, n * h->dim_pad8, nc * h->dim_pad8, false);
+    grow_copy(h->q8s_scale, n, nc + 256, true);
+    if (!h->s8_err) {
+      HX_HIP(hipMalloc((void**)&h->s8_err, 4));
+      HX_HIP(hipMemset(h->s8_err, 0, 4));
+    }
+  }
   for (int p = 0; p < h->n_pre; ++p) grow_copy(h->pre[p], n * h->psize[p], nc * h->psize[p], false);
   if (h->n_pre > 0) grow_copy(h->pre_h0, n * h->psize[0], nc * h->psize[0], false);
   h->cap = nc;
@@ -237,6 +258,9 @@ static void prep_rows_device(hx_index* h, const float* raw_dev, int64_t n, hipSt
     a.pre[p] = h->pre[p] + h->n * h->psize[p];
   }
   a.pre_h0 = h->n_pre > 0 ? h->pre_h0 + h->n * h->psize[0] : nullptr;
+  a.q8s = h->cand8 ? h->q8s + h->n * h->dim_pad8 : nullptr;
+  a.q8s_scale = h->cand8 ? h->q8s_scale + h->n : nullptr;
+  a.err_max = h->s8_err;
   launch_prep_rows(a, st);
 }
 
@@ -425,15 +449,25 @@ static int predict_rank(int Lp, double g_eff) {
   }
   return cache[key] = lo;
 }
-static Geometry geometry(int L, bool approx, bool safe) {
-  static thread_local std::map<std::tuple<int, bool, bool>, Geometry> cache;
-  const auto key = std::make_tuple(L, approx, safe);
+// cand8: the int8 candidate pass.  Its certificate radius (the row and query quantisation errors, ~8e-3 on unit
+// vectors of 768 uniform components, against 1.25e-3 for fp16) asks for more candidates: the L'-th best int8
+// score has to lie a radius below the exact L-th best.
+static int cand8_lprime(int L) {
+  static const int mul = getenv("HX_DEBUG_CAND8_MUL") ? std::max(1, atoi(getenv("HX_DEBUG_CAND8_MUL"))) : 4;
+  static const int add = getenv("HX_DEBUG_CAND8_ADD") ? std::max(0, atoi(getenv("HX_DEBUG_CAND8_ADD"))) : 288;
+  return std::min(std::max(mul * L, L + add), std::max(L, CAND_CAP / 4));
+}
+static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false) {
+  static thread_local std::map<std::tuple<int, bool, bool, bool>, Geometry> cache;
+  const auto key = std::make_tuple(L, approx, safe, cand8);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   Geometry g;
   g.Lp = approx ? L + std::max(32, L / 2) : L;
+  if (cand8) g.Lp = cand8_lprime(L);
   if (safe) g.Lp = std::min(std::max(2 * g.Lp, g.Lp + 256), CAND_CAP / 4);
   int c = next_pow2(std::max(8 * g.Lp, 1024));
+  if (cand8) c = std::max(c, 4096);
   g.C = safe ? CAND_CAP : std::min(c, CAND_CAP);
   HX_CHECK(g.Lp * 2 <= g.C && g.Lp >= L, "limit too large");
   g.predictive = false;
@@ -502,9 +536,12 @@ struct ProfScope {
 };
 
 // scan all rows with geometric chunks; leaves the best `keep` keys (sorted) in cand
+// int8 scans: `rinv_x` = the per-row factor of the score (f32(dot) * rinv_x[row]) * rinv_q[query], `tm` its tile maxima;
+// `prof_what` = the profile slot of the launches (hx_prof)
 static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t* Q, int64_t row_bytes, int B,
                          int bn, const Geometry& g, uint64_t* cand, int* cnt, int* ovf, float* tau,
-                         const float* rinv_q, hipStream_t st) {
+                         const float* rinv_q, hipStream_t st, const float* rinv_x = nullptr,
+                         hx_index::TileMax* tm = nullptr, int prof_what = -1) {
   ScanArgs a{};
   a.A = A;
   a.Q = Q;
@@ -517,21 +554,27 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   a.overflow = ovf;
   a.cap = g.C;
   a.id_base = h->id_base;
-  a.rinv_x = h->q8_rinv;
+  if (kind == KIND_I8 && !rinv_x) {
+    rinv_x = h->q8_rinv;
+    tm = &h->tm_q8;
+  }
+  a.rinv_x = rinv_x;
   a.rinv_q = rinv_q;
   if (kind == KIND_I8) {
-    if (h->q8_tile_max_rows != h->n) {   // rows were added since the last int8 scan
+    if (tm->rows != h->n) {   // rows were added since the last scan with these scales
       const int64_t tiles = (h->cap + 255) / 256;
-      if (tiles > h->q8_tile_max_cap) {
-        if (h->q8_tile_max) HX_HIP(hipFree(h->q8_tile_max));
-        HX_HIP(hipMalloc((void**)&h->q8_tile_max, (size_t)tiles * 4));
-        h->q8_tile_max_cap = tiles;
+      if (tiles > tm->cap) {
+        if (tm->v) HX_HIP(hipFree(tm->v));
+        tm->v = nullptr;
+        HX_HIP(hipMalloc((void**)&tm->v, (size_t)tiles * 4));
+        tm->cap = tiles;
       }
-      launch_tile_max(h->q8_rinv, h->n, h->q8_tile_max, st);
-      h->q8_tile_max_rows = h->n;
+      launch_tile_max(rinv_x, h->n, tm->v, st);
+      tm->rows = h->n;
     }
-    a.rinv_tile_max = h->q8_tile_max;
+    a.rinv_tile_max = tm->v;
   }
+  if (prof_what < 0) prof_what = kind;
   uint4* hitlog = nullptr;
   int* hitcnt = nullptr;
   int logcap = h->scan_logcap;
@@ -576,7 +619,7 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
       const double elems = kind == KIND_F16 ? (double)row_bytes / 2.0 : (double)row_bytes;
       // the profile counts the k_scan8 launches only (bn == 256): the first chunk is a few thousand rows
       // through k_scan and would only blur the per-launch average the roofline is quoted on
-      ProfScope ps(h, st, kind, 2.0 * B * rows * elems, rows * (double)row_bytes + (double)B * row_bytes,
+      ProfScope ps(h, st, prof_what, 2.0 * B * rows * elems, rows * (double)row_bytes + (double)B * row_bytes,
                    !(a.all_pass && bn == 256));
       if (a.all_pass && bn == 256) {
         // a few thousand rows: 128 x 128 tiles give four times the workgroups of the 256 x 256 form
@@ -724,15 +767,31 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
   int* fail = (int*)h->ws.get(WS_FAIL + wo, (size_t)B * 4);
   int* nfail = (int*)h->ws.get(WS_NFAIL + wo, 4);
   std::vector<int> sel;
-  if (m.m16) {
-    const Geometry g = geometry(L, true, level > 0);
+  // The candidate pass of the full-vector stage runs on the int8 matrix pipe (half the bytes, twice the rate of
+  // fp16) when the index holds the scaled int8 copy; a query it cannot certify is retried through the fp16 scan
+  // (level 1) like any other flagged query.  Final scores are spec_dot on the fp32 rows either way.
+  const bool use8 = h->cand8 && !h->cand8_off && h->q8s && prefix == 0 && level == 0;
+  if (m.m16 || use8) {
+    const Geometry g = geometry(L, true, level > 0, use8);
     uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND + wo, (size_t)B * g.C * 8);
     uint64_t* cand2 = (uint64_t*)h->ws.get(WS_CAND2 + wo, (size_t)B * g.C * 8);
     int* cnt = (int*)h->ws.get(WS_CNT + wo, (size_t)B * 4);
     int* ovf = (int*)h->ws.get(WS_OVF + wo, (size_t)B * 4);
     float* tau = (float*)h->ws.get(WS_TAU + wo, (size_t)B * 4);
-    chunked_scan(h, KIND_F16, (const uint8_t*)m.m16, (const uint8_t*)qh, (int64_t)m.dpad * 2, B, bn, g,
-                 cand, cnt, ovf, tau, nullptr, st);
+    const float* eps_q = nullptr;
+    if (use8) {
+      int8_t* q8 = (int8_t*)h->ws.get(WS_Q8S + wo, (size_t)Bpad * h->dim_pad8);
+      float* sq = (float*)h->ws.get(WS_SQ + wo, (size_t)Bpad * 4);
+      float* eq = (float*)h->ws.get(WS_EPSQ + wo, (size_t)B * 4);
+      launch_prep_queries_s8(qn, m.dpad, B, Bpad, h->dim_pad8, q8, sq, eq, h->s8_err, st);
+      chunked_scan(h, KIND_I8, (const uint8_t*)h->q8s, (const uint8_t*)q8, h->dim_pad8, B, bn, g, cand, cnt, ovf, tau,
+                   sq, st, h->q8s_scale, &h->tm_q8s, 3);
+      eps_q = eq;
+      h->cand8_queries += B;
+    } else {
+      chunked_scan(h, KIND_F16, (const uint8_t*)m.m16, (const uint8_t*)qh, (int64_t)m.dpad * 2, B, bn, g,
+                   cand, cnt, ovf, tau, nullptr, st);
+    }
     RescoreArgs r{};
     r.kind = KIND_F32;
     r.M = m.m32;
@@ -751,10 +810,11 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     launch_rescore_list(r, st);
     launch_compact(cand2, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
     HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
-    launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st);
+    launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st, eps_q);
     if (between) between();
     if (defer) return false;
     sel = read_failures(h, fail, nfail, B, st);
+    if (use8) h->cand8_failed += (int64_t)sel.size();
     if (!sel.empty() && level == 0) {
       retry_subset(h, q_dev, sel, L, out_keys, out_cnt, st, level,
                    [&](const float* qs, int ns, uint64_t* ks, int* cs) {
@@ -1279,6 +1339,7 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
     }
     h->psize[i] = msizes[i];
   }
+  if (const char* e = getenv("HX_DENSE_CAND")) h->cand8 = strcmp(e, "f16") == 0 ? 0 : 1;   // candidate pass: i8 (default) | f16
   if (const char* e = getenv("HX_DEBUG_SP_CUTSTEP")) h->sp_cut_step = std::max(0, atoi(e));
   if (const char* e = getenv("HX_DEBUG_SEG_DOCS")) {       // tests: force a segment size
     const int v = atoi(e);
@@ -1300,9 +1361,9 @@ int hx_destroy(hx_index* h) {
   h->set_device();
   (void)hipDeviceSynchronize();
   free_sparse_index(h);
-  if (h->q8_tile_max) (void)hipFree(h->q8_tile_max);
   void* ptrs[] = {h->dense, h->dense_h, h->q8, h->q8_rinv, h->pre[0], h->pre[1], h->pre[2], h->pre_h0,
-                  h->sp_indptr, h->sp_idx, h->sp_val, h->sp_counter};
+                  h->sp_indptr, h->sp_idx, h->sp_val, h->sp_counter, h->q8s, h->q8s_scale, h->s8_err,
+                  h->tm_q8.v, h->tm_q8s.v};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->pin) (void)hipHostFree(h->pin);
@@ -1519,7 +1580,7 @@ int hx_truncate(hx_index* h, int64_t n_rows) {
   h->ids.next = -1;
   if (n_rows == h->n && h->sp_rows <= n_rows) return 0;
   h->n = n_rows;
-  h->q8_tile_max_rows = -1;
+  h->tm_q8.rows = h->tm_q8s.rows = -1;
   if (h->sp_rows > n_rows) {
     int64_t nnz = 0;
     if (n_rows > 0) HX_HIP(hipMemcpy(&nnz, h->sp_indptr + n_rows, 8, hipMemcpyDeviceToHost));
@@ -1876,6 +1937,25 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   out->i8_fallback_queries = h->i8_fallbacks;
   out->retry_queries = h->retries;
   out->sparse_fallback_queries = h->sparse_fallbacks;
+  out->bytes_i8_cand = h->q8s ? h->n * h->dim_pad8 + h->n * 4 : 0;
+  out->cand8_queries = h->cand8_queries;
+  out->cand8_uncertified_queries = h->cand8_failed;
+  float emax = 0.f;
+  if (h->s8_err) {
+    h->set_device();
+    HX_HIP(hipMemcpy(&emax, h->s8_err, 4, hipMemcpyDeviceToHost));
+  }
+  out->cand8_row_error_max = (double)emax;
+  HX_CATCH
+}
+
+int hx_set_dense_candidates(hx_index* h, int32_t kind) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  HX_CHECK(kind == 0 || kind == 1, "kind: 0 = fp16 candidates, 1 = int8 candidates");
+  HX_CHECK(kind == 0 || h->q8s || h->n == 0, "this index holds no int8 candidate copy (created with HX_DENSE_CAND=f16)");
+  if (kind == 1 && !h->q8s) h->cand8 = 1;     // empty index: the copy is made as rows arrive
+  h->cand8_off = kind == 0;
   HX_CATCH
 }
 
@@ -1895,7 +1975,7 @@ int hx_profile_read(hx_index* h, hx_prof* out) {
     HX_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
     HX_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-    const int w = r.what;  // 0 f16 scan, 1 i8 scan, 2 sparse
+    const int w = r.what;  // 0 f16 scan, 1 i8 scan ("quantized" stage), 2 sparse select, 3 int8 candidate scan of the dense stage
     out->launches[w] += 1;
     out->ms[w] += ms;
     out->flops[w] += r.flops;
@@ -2073,6 +2153,8 @@ int hx_load(const char* path, int32_t device, hx_index** out) {
     for (int p = 0; p < h->n_pre; ++p) file_to_dev(fl.f, h->pre[p], n * h->psize[p] * 4, buf);
     if (h->n_pre > 0) file_to_dev(fl.f, h->pre_h0, n * h->psize[0] * 2, buf);
     h->n = hd.n;
+    // the candidate copy is derived data (not in the file): one pass over the stored rows
+    if (h->cand8) launch_requant_rows(h->dense, h->dim_pad, h->dim_pad8, hd.n, h->q8s, h->q8s_scale, h->s8_err, nullptr);
     if (hd.sp_rows > 0) {
       reserve_sparse(h, hd.sp_rows, hd.nnz);
       file_to_dev(fl.f, h->sp_indptr, ((size_t)hd.sp_rows + 1) * 8, buf);

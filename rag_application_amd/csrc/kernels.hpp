@@ -118,9 +118,11 @@ struct RangeArgs {
 void launch_rescore_range(const RangeArgs& a, hipStream_t st);
 
 // fail[b] = overflow[b] || (approx_cnt[b] >= lprime && !(approx_Lprime_score + eps < exact_L_score))
+// eps_q (optional): a radius per query instead of the common `eps`
 void launch_certify(const uint64_t* approx_keys, int approx_stride, const int* approx_cnt, int lprime,
                     const uint64_t* exact_keys, int exact_stride, const int* exact_cnt, int L,
-                    const int* overflow, float eps, int B, int* fail, int* nfail, hipStream_t st);
+                    const int* overflow, float eps, int B, int* fail, int* nfail, hipStream_t st,
+                    const float* eps_q = nullptr);
 
 void launch_rrf(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride,
                 const int* b_cnt, int B, float k, int rank_base, int limit, uint64_t* out,
@@ -153,8 +155,19 @@ struct PrepRowsArgs {
   int psize[3];
   float* pre[3];           // [n x psize] normalised prefixes of the RAW row
   _Float16* pre_h0;        // fp16 copy of prefix 0 (may be NULL)
+  // candidate-pass copy of the NORMALISED row (may be NULL): rint(x * 127 / max|x|), its scale max|x| / 127, and
+  // the running maximum over all rows of the quantisation error ||x - scale * x8||_2 (fp32 bits, rounded up)
+  int8_t* q8s;             // [n x dim_pad8]
+  float* q8s_scale;        // [n]
+  uint32_t* err_max;       // one device word
 };
 void launch_prep_rows(const PrepRowsArgs& a, hipStream_t st);
+void launch_requant_rows(const float* dense, int dim_pad, int dim_pad8, int64_t n, int8_t* q8s, float* scale,
+                         uint32_t* err_max, hipStream_t st);
+// candidate-pass form of normalised queries qn [B x dpad]: int8 rows [Bpad x dpad8], scales [Bpad], certificate
+// radius per query [B] from the index's largest row quantisation error (*err_max)
+void launch_prep_queries_s8(const float* qn, int dpad, int B, int Bpad, int dpad8, int8_t* q8, float* sq, float* eps,
+                            const uint32_t* err_max, hipStream_t st);
 // out[t] = max of the non-negative floats p[256 t, 256 t + 256) (clipped to n)
 void launch_tile_max(const float* p, int64_t n, float* out, hipStream_t st);
 void launch_synth_dense(float* raw, int64_t row0_global, int64_t n, int dim, uint32_t seed, hipStream_t st);

@@ -100,37 +100,41 @@ __global__ __launch_bounds__(NT) void k_compact(const uint64_t* __restrict__ key
 }
 
 // ---------------------------------------------------------------------------------
-// compaction, short form: keep <= 256 of <= 2048 keys, no dedupe.  Same results as
-// k_compact, but no block-wide sort: every wave sorts 256 keys in registers (4 per lane;
-// strides below 4 are register swaps, the rest lane exchanges -- no LDS traffic of its
-// own, no barrier), then log2(NW) rounds fold the waves pairwise: max(A[i], B[255 - i])
-// of two descending runs is a bitonic run holding the best 256 of both, sorted again by
-// the last 8 stages.  One barrier per round instead of one per stage (66 at P = 2048).
+// compaction, short form: keep <= 64 E of <= NW * 64 E keys, no dedupe (E = 4: 256 of <= 2048 -- every
+// compaction of the fp16-candidate step; E = 8: 512 of <= 8192 -- the int8 candidate pass keeps more
+// candidates).  Same results as k_compact, but no block-wide sort: every wave sorts 64 E keys in registers
+// (E per lane; strides below E are register swaps, the rest lane exchanges -- no LDS traffic of its own, no
+// barrier), then log2(NW) rounds fold the waves pairwise: max(A[i], B[64 E - 1 - i]) of two descending runs
+// is a bitonic run holding the best 64 E of both, sorted again by the last stages.  One barrier per round
+// instead of one per stage (66 at P = 2048).
 // ---------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_compact_top256(const uint64_t* __restrict__ keys, int stride,
-                                                            const int* __restrict__ in_cnt, int keep,
-                                                            uint64_t* out_keys, int out_stride, int* out_cnt,
-                                                            float* tau, int tau_rank, int chk_rank, int* kept_io,
-                                                            int* underflow) {
-  __shared__ uint64_t buf[NW > 1 ? NW * 256 : 1];
+template <int NW, int E>
+__global__ __launch_bounds__(NW * 64) void k_compact_top(const uint64_t* __restrict__ keys, int stride,
+                                                         const int* __restrict__ in_cnt, int keep,
+                                                         uint64_t* out_keys, int out_stride, int* out_cnt,
+                                                         float* tau, int tau_rank, int chk_rank, int* kept_io,
+                                                         int* underflow) {
+  constexpr int R = 64 * E;          // keys per wave
+  // a wave hands its run to its partner through slot w / 2: the only earlier reader of that slot is the wave itself
+  // (as the partner of wave w + 1 in the first round), so NW / 2 slots serve every round
+  __shared__ uint64_t buf[NW > 1 ? (NW / 2) * R : 1];
   __shared__ int s_tot[NW];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int n = in_cnt ? in_cnt[b] : stride;
   const int n_raw = n;
   n = n < stride ? n : stride;
-  n = n < NW * 256 ? n : NW * 256;
+  n = n < NW * R ? n : NW * R;
   const uint64_t* src = keys + (int64_t)b * stride;
-  uint64_t v[4];
+  uint64_t v[E];
   int tot = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {   // the order inside an unsorted run is free: coalesced loads
-    const int i = w * 256 + e * 64 + lane;
+  for (int e = 0; e < E; ++e) {   // the order inside an unsorted run is free: coalesced loads
+    const int i = w * R + e * 64 + lane;
     v[e] = i < n ? src[i] : 0ull;
     tot += __popcll(__ballot(v[e] != 0ull));
   }
-  if (n > w * 256) w_sort<256>(v, lane);
+  if (n > w * R) w_sort<R>(v, lane);
   if (NW > 1) {
     if (lane == 0) s_tot[w] = tot;
 #pragma unroll
@@ -138,14 +142,14 @@ __global__ __launch_bounds__(NW * 64) void k_compact_top256(const uint64_t* __re
       const int m = (2 << s) - 1;
       if ((w & m) == (1 << s)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) buf[w * 256 + lane * 4 + e] = v[e];
+        for (int e = 0; e < E; ++e) buf[(w >> 1) * R + lane * E + e] = v[e];
       }
       __syncthreads();   // also: every wave's loads have landed before any store below (in-place use)
       const int pw = w + (1 << s);
-      if ((w & m) == 0 && n > pw * 256) {
+      if ((w & m) == 0 && n > pw * R) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = k64max(v[e], buf[pw * 256 + 255 - (lane * 4 + e)]);
-        w_merge<256, 128>(v, lane);
+        for (int e = 0; e < E; ++e) v[e] = k64max(v[e], buf[(pw >> 1) * R + (R - 1) - (lane * E + e)]);
+        w_merge<R, R / 2>(v, lane);
       }
     }
     tot = 0;
@@ -154,16 +158,18 @@ __global__ __launch_bounds__(NW * 64) void k_compact_top256(const uint64_t* __re
   }
   uint64_t* o = out_keys + (int64_t)b * out_stride;
   const int kept = tot < keep ? tot : keep;
-  for (int i = 256 + tid; i < out_stride; i += NW * 64) o[i] = 0ull;
+  for (int i = R + tid; i < out_stride; i += NW * 64) o[i] = 0ull;
   if (w == 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = lane * 4 + e;
+    for (int e = 0; e < E; ++e) {
+      const int i = lane * E + e;
       if (i < out_stride) o[i] = i < kept ? v[e] : 0ull;   // empty slots are 0
     }
     const int kr = tau_rank - 1;
-    const uint64_t mine = (kr & 3) == 0 ? v[0] : ((kr & 3) == 1 ? v[1] : ((kr & 3) == 2 ? v[2] : v[3]));
-    const uint64_t kth = (uint64_t)__shfl((unsigned long long)mine, kr >> 2, 64);
+    uint64_t mine = v[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) mine = (kr & (E - 1)) == e ? v[e] : mine;
+    const uint64_t kth = (uint64_t)__shfl((unsigned long long)mine, kr / E, 64);
     if (lane == 0) {
       out_cnt[b] = kept;
       if (tau) tau[b] = (tot >= keep && keep > 0) ? key_score(kth) : -__builtin_inff();
@@ -184,20 +190,31 @@ void launch_compact(uint64_t* keys, int stride, const int* in_cnt, int B, int ke
   int P = next_pow2(m < 256 ? 256 : m);
   HX_CHECK(P <= CAND_CAP, "compact: list longer than CAND_CAP");
   HX_CHECK(keep <= out_stride, "compact: keep > out_stride");
+#define HX_TOP(NW, E)                                                                                            \
+  hipLaunchKernelGGL((k_compact_top<NW, E>), dim3(B), dim3(NW * 64), 0, st, keys, stride, in_cnt, keep, out_keys, \
+                     out_stride, out_cnt, tau, tau_rank, chk_rank, kept_io, underflow)
   if (!dedupe && keep >= 1 && keep <= 256 && P <= 2048) {   // short form; the tau rank is <= keep
     if (tau_rank <= 0 || tau_rank > keep) tau_rank = keep;
     HX_CHECK(!kept_io || underflow, "compact: kept_io without an underflow flag array");
-#define HX_TOP256(NW)                                                                                          \
-  hipLaunchKernelGGL(k_compact_top256<NW>, dim3(B), dim3(NW * 64), 0, st, keys, stride, in_cnt, keep, out_keys, \
-                     out_stride, out_cnt, tau, tau_rank, chk_rank, kept_io, underflow)
-    if (P <= 256) HX_TOP256(1);
-    else if (P <= 512) HX_TOP256(2);
-    else if (P <= 1024) HX_TOP256(4);
-    else HX_TOP256(8);
-#undef HX_TOP256
+    if (P <= 256) HX_TOP(1, 4);
+    else if (P <= 512) HX_TOP(2, 4);
+    else if (P <= 1024) HX_TOP(4, 4);
+    else HX_TOP(8, 4);
     HX_HIP(hipGetLastError());
     return;
   }
+  if (!dedupe && keep > 256 && keep <= 512 && P <= 8192) {  // ... with 8 keys per lane: the int8 candidate pass
+    if (tau_rank <= 0 || tau_rank > keep) tau_rank = keep;
+    HX_CHECK(!kept_io || underflow, "compact: kept_io without an underflow flag array");
+    if (P <= 512) HX_TOP(1, 8);
+    else if (P <= 1024) HX_TOP(2, 8);
+    else if (P <= 2048) HX_TOP(4, 8);
+    else if (P <= 4096) HX_TOP(8, 8);
+    else HX_TOP(16, 8);
+    HX_HIP(hipGetLastError());
+    return;
+  }
+#undef HX_TOP
   {   // the dynamic-LDS opt-in is a property of the function ON A DEVICE: once per device, under a lock
     static std::mutex mu;
     static bool attr_set[64] = {};
@@ -326,9 +343,10 @@ void launch_rescore_range(const RangeArgs& a, hipStream_t st) {
 __global__ void k_certify(const uint64_t* approx_keys, int approx_stride, const int* approx_cnt,
                           int lprime, const uint64_t* exact_keys, int exact_stride,
                           const int* exact_cnt, int L, const int* overflow, float eps, int B, int* fail,
-                          int* nfail) {
+                          int* nfail, const float* eps_q) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (eps_q) eps = eps_q[b];
   bool bad = overflow[b] != 0;
   if (!bad && approx_cnt[b] >= lprime) {
     // candidate list is full: rows outside it have approx score <= m
@@ -347,10 +365,11 @@ __global__ void k_certify(const uint64_t* approx_keys, int approx_stride, const 
 
 void launch_certify(const uint64_t* approx_keys, int approx_stride, const int* approx_cnt, int lprime,
                     const uint64_t* exact_keys, int exact_stride, const int* exact_cnt, int L,
-                    const int* overflow, float eps, int B, int* fail, int* nfail, hipStream_t st) {
+                    const int* overflow, float eps, int B, int* fail, int* nfail, hipStream_t st,
+                    const float* eps_q) {
   hipLaunchKernelGGL(k_certify, dim3((B + 255) / 256), dim3(256), 0, st, approx_keys, approx_stride,
                      approx_cnt, lprime, exact_keys, exact_stride, exact_cnt, L, overflow, eps, B, fail,
-                     nfail);
+                     nfail, eps_q);
   HX_HIP(hipGetLastError());
 }
 

@@ -166,13 +166,17 @@ class HxIndex:
         check(_lib.lib().hx_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in HxStats._fields_}
 
+    def set_dense_candidates(self, kind: str):
+        """'i8' (default) or 'f16': which copy nominates the dense stage's candidates (hx_set_dense_candidates)."""
+        check(_lib.lib().hx_set_dense_candidates(self._h, {"f16": 0, "i8": 1}[kind]))
+
     def profile(self, enable: bool):
         check(_lib.lib().hx_profile(self._h, 1 if enable else 0))
 
     def profile_read(self) -> dict:
         p = HxProf()
         check(_lib.lib().hx_profile_read(self._h, C.byref(p)))
-        names = ("scan_f16", "scan_i8", "sparse")
+        names = ("scan_f16", "scan_i8", "sparse", "scan_cand8")
         return {n: dict(launches=p.launches[i], ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i])
                 for i, n in enumerate(names)}
 

@@ -1,0 +1,69 @@
+"""A/B of the dense stage's candidate pass on the bench workload: int8 copy (default) vs fp16 copy.
+python scripts/cand8_ab.py [rows] [batch] [steps]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rag_application_amd import engine as eng, synth
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+dim = 768
+tabs = synth.tables()
+ix = eng.HxIndex(dim, (64, 128, 256))
+ix.reserve(rows)
+t0 = time.perf_counter()
+ix.synth_fill(rows, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs)
+ix.finalize()
+torch.cuda.synchronize()
+print("build s", time.perf_counter() - t0, flush=True)
+Q = eng.synth_queries_dense(dim, 0, B, synth.SEED_QUERY)
+qip, qix, qv = synth.sparse_queries(synth.SEED_SPQUERY, 0, B, tabs)
+sp = tuple(torch.from_numpy(a).cuda() for a in (qip, qix, qv))
+P = dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=60, dense_limit=100,
+         quantized_limit=40, sparse_limit=100, final_limit=10, hnsw_ef=128)
+hp = eng.make_params(P, mode=eng.HX_MODE_H1)
+out = {}
+ref = None
+for kind in ("i8", "f16", "i8"):
+    ix.set_dense_candidates(kind)
+    for _ in range(2):
+        r = ix.hybrid_query(Q, *sp, hp)
+    torch.cuda.synchronize()
+    ix.profile(True)
+    ix.profile_read()
+    s0 = ix.stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = ix.hybrid_query(Q, *sp, hp)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pr = ix.profile_read()
+    ix.profile(False)
+    s1 = ix.stats()
+    if ref is None:
+        ref = r
+    same = bool(torch.equal(ref[0], r[0]) and torch.equal(ref[1], r[1]))
+    d = dict(ms_per_step=dt * 1e3, qps=B / dt, same_lists_as_first=same,
+             uncertified=s1["cand8_uncertified_queries"] - s0["cand8_uncertified_queries"],
+             retries=s1["retry_queries"] - s0["retry_queries"], exact_fallbacks=s1["dense_fallback_queries"] - s0["dense_fallback_queries"],
+             row_err_max=s1["cand8_row_error_max"])
+    for k, v in pr.items():
+        if v["launches"]:
+            d[k] = dict(launches_per_step=v["launches"] / steps, ms_per_step=v["ms"] / steps,
+                        tflops=v["flops"] / v["ms"] / 1e9 if v["ms"] else None, gbs=v["bytes"] / v["ms"] / 1e6 if v["ms"] else None)
+    out[kind + ("_again" if kind in out else "")] = d
+    print(kind, json.dumps(d), flush=True)
+# dense-only small batches: the bandwidth-bound side
+for b in (1, 8, 32):
+    q = Q[:b].contiguous()
+    for kind in ("i8", "f16"):
+        ix.set_dense_candidates(kind)
+        ix.search_dense(q, 10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ix.search_dense(q, 10)
+        torch.cuda.synchronize()
+        print("dense B", b, kind, "ms", (time.perf_counter() - t0) / 5 * 1e3, flush=True)
+print(json.dumps(out))

@@ -167,11 +167,12 @@ def test_rescore_rrf_merge(small, eng, torch_mod):
         np.testing.assert_array_equal(keys[b].cpu().numpy().view(np.uint64)[:len(u)], u)
 
 
-@pytest.mark.parametrize("stride", [100, 256, 257, 600, 1024, 1500, 2048, 4096])
+@pytest.mark.parametrize("stride", [100, 256, 257, 600, 1024, 1500, 2048, 4096, 5000, 8192])
 @pytest.mark.parametrize("dedupe", [False, True])
 def test_compaction_all_sizes(eng, torch_mod, stride, dedupe):
     """hx_merge == sorted (descending) distinct non-zero keys of each list, cut to the limit: the
-    in-register short form (limit <= 256 of <= 2048 keys) and the LDS sort give the same lists."""
+    in-register short forms (limit <= 256 of <= 2048 keys, 4 keys per lane; limit <= 512 of <= 8192, 8 per lane)
+    and the LDS sort give the same lists."""
     rng = np.random.default_rng(1000 + stride)
     B = 37
     pool = rng.integers(1, 2 ** 63 - 1, size=(B, stride), dtype=np.int64)
@@ -180,7 +181,7 @@ def test_compaction_all_sizes(eng, torch_mod, stride, dedupe):
         pool[:, stride // 2:] = pool[:, :stride - stride // 2]  # every key twice
     cnt = rng.integers(0, stride + 1, size=B).astype(np.int32)
     cnt[0], cnt[1], cnt[2] = 0, stride, 1
-    for limit in (1, 10, 150, 256, 300):
+    for limit in (1, 10, 150, 256, 257, 300, 400, 512, 513):
         if limit > stride:
             continue
         for counts in (None, cnt):
@@ -901,12 +902,14 @@ def test_scan8_underflow_retry(eng, torch_mod, monkeypatch, order):
     ix = eng.HxIndex(dim, ())
     ix.add(X)
     es, ei, ec = _c_expected_dense(X, Q, limit)
-    keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit)
-    s, i, c = unpack_np(eng, keys, cnt)
-    for b in range(B):
-        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"underflow b={b}")
-    if order == "physical":
-        assert ix.stats()["retry_queries"] > 0, "the underflow path was not exercised"
+    for kind in ("f16", "i8"):       # (the int8 candidate pass keeps ~300 candidates: the 800 planted rows do not starve it)
+        ix.set_dense_candidates(kind)
+        keys, cnt = ix.search_dense(torch_mod.from_numpy(Q).cuda(), limit)
+        s, i, c = unpack_np(eng, keys, cnt)
+        for b in range(B):
+            assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"underflow {kind} b={b}")
+        if order == "physical" and kind == "f16":
+            assert ix.stats()["retry_queries"] > 0, "the underflow path was not exercised"
     assert ix.stats()["dense_fallback_queries"] == 0
     ix.close()
 
@@ -1293,3 +1296,78 @@ def test_load_refuses_a_repeated_term_id(eng, torch_mod, synth_tables, tmp_path)
     with pytest.raises(eng.HxError, match="repeats"):
         eng.HxIndex.load(bad)
     ix.close()
+
+
+# ---- the dense stage's int8 candidate pass (per-row-scaled copy + data-dependent certificate) ------------------------------
+@pytest.mark.parametrize("n,dim,B,L", [(30000, 768, 9, 10), (30000, 768, 300, 100), (20000, 384, 257, 10), (9000, 100, 40, 50),
+                                       (40000, 1024, 130, 200)])
+def test_dense_candidates_int8_and_fp16_give_the_exact_lists(eng, torch_mod, n, dim, B, L):
+    """The full-vector dense stage nominates candidates on the int8 copy (default) or on the fp16 copy: both return
+    the exact fp32 lists of the C restatement, bit for bit; the stats say which pass served the queries."""
+    from oracle import c_oracle as CO
+    X = O.synth_dense(31, 0, n, dim) * np.float32(2.5)
+    Q = O.synth_dense(32, 0, B, dim) * np.float32(0.3)
+    es, ei, ec = CO.search_dense(CO.cosine_preprocess(X), CO.cosine_preprocess(Q), L)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    for kind in ("i8", "f16", "i8"):
+        ix.set_dense_candidates(kind)
+        before = ix.stats()["cand8_queries"]
+        s, i, c = unpack_np(eng, *ix.search_dense(Qd, L))
+        for b in range(B):
+            assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"{kind} candidates n={n} dim={dim} b={b}")
+        assert (ix.stats()["cand8_queries"] - before) == (B if kind == "i8" else 0)
+    st = ix.stats()
+    assert 0.0 < st["cand8_row_error_max"] < 0.05 and st["bytes_i8_cand"] > 0
+    assert st["cand8_uncertified_queries"] <= B // 4 + 1, st      # uniform rows: the certificate holds (almost) always
+    ix.close()
+
+
+def test_int8_candidates_fall_back_when_the_certificate_cannot_hold(eng, torch_mod):
+    """Rows the int8 grid cannot resolve: (a) one dominant component per row (the row's scale is set by it, the other
+    767 components fall into a handful of levels), (b) a tight cluster around the query (scores differ in the 5th
+    digit).  The certificate fails, the queries are re-run on the fp16 copy (and beyond), the lists stay exact."""
+    from oracle import c_oracle as CO
+    n, dim, B, L = 20000, 768, 140, 20
+    rng = np.random.default_rng(5)
+    X = O.synth_dense(41, 0, n, dim)
+    X[np.arange(n), rng.integers(0, dim, n)] = 40.0                      # (a)
+    Q = O.synth_dense(42, 0, B, dim)
+    Q[:20] = X[:20] + 0.05 * O.synth_dense(43, 0, 20, dim)
+    X[1000:1400] = Q[3] + 1e-3 * O.synth_dense(44, 0, 400, dim)          # (b) 400 rows within 1e-5 of each other
+    es, ei, ec = CO.search_dense(CO.cosine_preprocess(X), CO.cosine_preprocess(Q), L)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    s, i, c = unpack_np(eng, *ix.search_dense(torch_mod.from_numpy(Q).cuda(), L))
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"b={b}")
+    st = ix.stats()
+    assert st["cand8_queries"] == B and st["cand8_uncertified_queries"] > 0, st
+    assert st["cand8_row_error_max"] > 0.05, st                           # the bound knows the rows are coarse
+    ix.close()
+
+
+def test_int8_candidate_copy_survives_save_load_and_truncate(eng, torch_mod, tmp_path):
+    """The candidate copy is derived data: hx_load rebuilds it from the stored rows (same lists, same error bound),
+    hx_truncate keeps a valid bound."""
+    n, dim, B, L = 12000, 256, 150, 30
+    X = O.synth_dense(51, 0, n, dim)
+    Qd = torch_mod.from_numpy(O.synth_dense(52, 0, B, dim)).cuda()
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    path = str(tmp_path / "c.hx")
+    ix.save(path)
+    ld = eng.HxIndex.load(path)
+    k0, c0 = ix.search_dense(Qd, L)
+    k1, c1 = ld.search_dense(Qd, L)
+    assert torch_mod.equal(k0, k1) and torch_mod.equal(c0, c1)
+    assert ld.stats()["cand8_queries"] == B and ld.stats()["cand8_row_error_max"] == ix.stats()["cand8_row_error_max"]
+    ld.truncate(7000)
+    ref = eng.HxIndex(dim, ())
+    ref.add(X[:7000])
+    k2, c2 = ld.search_dense(Qd, L)
+    k3, c3 = ref.search_dense(Qd, L)
+    assert torch_mod.equal(k2, k3) and torch_mod.equal(c2, c3)
+    for i in (ix, ld, ref):
+        i.close()
