@@ -4,8 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4]
 
 One "step" = one batch of B queries through the hot path with every input already
-resident in HBM: per-shard cosine top-100 (fp16 MFMA scan + exact fp32 re-score,
-certified) and BM25 top-100 over the on-device inverted index, per-stage all-gather of
+resident in HBM: per-shard cosine top-100 (int8 MFMA candidate scan + exact fp32
+re-score, certified) and BM25 top-100 over the on-device inverted index, per-stage all-gather of
 the shards' lists over RCCL (N > 1), reciprocal-rank fusion, top-10.  The corpus is
 row-sharded over the N ranks (strong scaling: total work is fixed).  Rank 0 prints one
 JSON line; see DESIGN.md "Measurement" for every field."""
@@ -31,9 +31,12 @@ WORKLOADS = {
                  desc="100M x 768 row-sharded dense top-10, batch 1024 (needs 8 GPUs)"),
 }
 PEAK_FP16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_I8_TOPS = 5000.0       # MI355X dense int8 MFMA: twice the fp16 rate (same guide, MFMA table)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
 SPARSE_ARITH = "16-bit integer select pass over the inverted index + exact re-score in upstream order (fp32 running sum, ascending term id)"
-PMC_PROFILE = "r02_pmc_scan.json"   # committed rocprofv3 --pmc pass the `traffic` figure is read from
+DENSE_ARITH = ("int8 MFMA candidate scan over a per-row-scaled int8 copy of the normalised rows + exact fp32 re-score of "
+               "the candidates, certified per query (a query the certificate does not cover is re-run on the fp16 copy)")
+PMC_PROFILE = "r03_pmc_scan.json"   # committed rocprofv3 --pmc pass the `traffic` figure is read from
 
 
 def parse():
@@ -48,7 +51,8 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=64,
                     help="queries of the timed batch brute-forced on the host over the WHOLE corpus")
     ap.add_argument("--no-secondary", action="store_true", help="skip tree mode / cfg2 / small-batch side measurements")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (box share per GPU)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads of the CPU baseline (0 = host cores / GPUs of the host: the box share of one GPU)")
     return ap.parse_args()
 
 
@@ -66,7 +70,36 @@ def _merge_best(best, s, i, c, L):
     return out
 
 
-def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000):
+def host_share():
+    """(threads, note): the host cores that belong to one GPU of this box = cores the process may run on, divided by
+    the GPUs of the host (KFD topology: every GPU of the machine is listed there even when one is handed to us)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    gpus = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for nd in os.listdir(root):
+            with open(os.path.join(root, nd, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            gpus += 1 if int(props.get("simd_count", "0")) > 0 else 0
+    except OSError:
+        pass
+    if gpus <= 0:
+        import torch
+        gpus = max(torch.cuda.device_count(), 1)
+    return max(1, cores // gpus), f"{cores} usable host cores / {gpus} GPUs on the host"
+
+
+def _median3(fn):
+    """(median seconds of three runs, result of the last)"""
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[1], r
+
+
+def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000, share_note=""):
     """The C restatement of the path (oracle/hx_oracle.c, kind "port") timed on this box's host cores on a
     bounded sample: the queries `sel` of the timed batch, brute force over the WHOLE corpus (regenerated
     chunk by chunk, never resident at once).  The lists it produces are then compared -- ids and fp32 score
@@ -95,16 +128,14 @@ def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000):
     for r0 in range(0, rows, chunk_rows):
         n = min(chunk_rows, rows - r0)
         Xn = CO.cosine_preprocess(CO.synth_dense(synth.SEED_CORPUS, r0, n, dim))
-        t0 = time.perf_counter()
-        s, i, c = CO.search_dense(Xn, Qn, L, id_base=r0)
-        t_cpu += time.perf_counter() - t0
+        dt, (s, i, c) = _median3(lambda: CO.search_dense(Xn, Qn, L, id_base=r0))
+        t_cpu += dt
         del Xn
         dbest = _merge_best(dbest, s, i, c, L)
         if mode == "h1":
             ip, ix, v = CO.synth_sparse_docs(synth.SEED_SPDOC, r0, n, tabs)
-            t0 = time.perf_counter()
-            s, i, c = CO.sparse_brute(ip, ix, v, qip, qix, qv, L, id_base=r0)
-            t_cpu += time.perf_counter() - t0
+            dt, (s, i, c) = _median3(lambda: CO.sparse_brute(ip, ix, v, qip, qix, qv, L, id_base=r0))
+            t_cpu += dt
             del ip, ix, v
             sbest = _merge_best(sbest, s, i, c, L)
     t0 = time.perf_counter()
@@ -127,19 +158,55 @@ def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000):
                 build=CPU_BUILD,
                 sample=f"{bs} of {wl['batch']} queries of the timed batch (every {wl['batch'] // bs}th) x ALL {rows} rows, "
                        f"brute force chunk by chunk ({t_cpu:.2f} s of CPU search work, data generation not counted); "
-                       f"document-at-a-time sparse scoring; one timing, {threads} of {os.cpu_count()} host cores",
+                       f"document-at-a-time sparse scoring; every chunk's search timed three times, the medians summed; "
+                       f"{threads} threads = {share_note}",
                 parity_on_sample=bool(ok), recall_at_10=(hit / want if want else None),
                 checked="ids and fp32 score bits of the LAST TIMED STEP's lists for the sampled queries")
 
 
-def ingest_leg(eng, torch, local, t_build, rows, nnz):
-    """BASELINE config 5 on one GPU: the index build of this run (timed around synth_fill + finalize, so it
-    includes generating the synthetic rows) and a bounded run of the 'batched encode' leg -- a bge-base-shaped
-    BERT (random init: no checkpoint ships), bf16, the reference's unmasked mean pooling
-    (app/core/models/huggingface/huggingface.py:165-170), its output appended where it lies (hx_add_dense_dev)."""
-    out = dict(what="config 5 legs on ONE GPU (ranks ingest their own deal of the chunks: sharded.ShardedCollection.store)",
-               index_build=dict(rows=rows, postings=nnz, seconds_incl_synthetic_generation=t_build,
-                                chunks_per_sec=rows / t_build))
+def ingest_leg(eng, synth, torch, local, t_build, rows, nnz, tabs):
+    """BASELINE config 5 on one GPU, chunks/sec (ranks ingest their own deal of the chunks:
+    sharded.ShardedCollection.store).  Three legs:
+      store_from_host   what store_document_vectors hands over (qdrant_handler.py:120-198): fp32 rows + the sparse CSR
+                        in host memory -> hx_add_rows (PCIe-inclusive: pageable host buffers, staged 65536 rows at a
+                        time) -> the inverted index over them (K9);
+      store_from_device the same rows already in HBM, as an encoder on this GPU leaves them -> hx_add_rows_dev;
+      encode_and_append a bge-base-shaped BERT (random init: no checkpoint ships), bf16, the reference's unmasked mean
+                        pooling (app/core/models/huggingface/huggingface.py:165-170), output appended where it lies.
+    K1/K2 (k_prep_rows) is reported against the HBM roofline from HIP events around its launches (hx_profile slot 4:
+    the raw row read once, every derived copy written once)."""
+    out = dict(what="config 5 legs on ONE GPU",
+               synthetic_index_build=dict(rows=rows, postings=nnz, seconds_incl_generation_on_device=t_build,
+                                          note="rows generated ON the device (hx_synth_fill): not an ingest rate"))
+    try:
+        n_ing, dim = 131072, 768
+        X, ip, ix_, v = synth.ingest_batch(7, n_ing, dim, tabs)   # host arrays of the corpus' shape (not its stream)
+        for leg in ("store_from_host", "store_from_device"):
+            sc = eng.HxIndex(dim, (64, 128, 256), device=local)
+            sc.reserve(n_ing, int(ip[-1]))
+            Xd = torch.from_numpy(X).to(f"cuda:{local}") if leg == "store_from_device" else None
+            sc.profile(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if Xd is None:
+                sc.add(X, ip, ix_, v)
+            else:
+                sc.add_device(Xd, ip, ix_, v)
+            t_add = time.perf_counter() - t0
+            sc.finalize()
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            pr = sc.profile_read()["prep_rows"]
+            out[leg] = dict(chunks=n_ing, postings=int(ip[-1]), chunks_per_sec=n_ing / t_all, seconds_add=t_add,
+                            seconds_index_build=t_all - t_add,
+                            k_prep_rows=dict(launches=pr["launches"], ms=pr["ms"], alg_gb=pr["bytes"] / 1e9,
+                                             gbs=pr["bytes"] / pr["ms"] / 1e6 if pr["ms"] else None,
+                                             frac_of_hbm_peak=pr["bytes"] / pr["ms"] / 1e6 / PEAK_HBM_GBS if pr["ms"] else None))
+            sc.close()
+            del Xd
+        del X
+    except Exception as e:
+        out["store_error"] = repr(e)[:300]
     try:
         from transformers import BertConfig, BertModel
         Bn, S, NB = 256, 128, 12
@@ -175,7 +242,7 @@ def ingest_leg(eng, torch, local, t_build, rows, nnz):
     return out
 
 
-def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, steps=3):
+def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, hp_h1=None, last_res=None, steps=3):
     """Side measurements on the driver record: the reference tree on the same index, the
     bandwidth-bound dense kNN (B = 1 / 8 / 32) on the same corpus, and BASELINE config 2."""
     out = {}
@@ -194,11 +261,29 @@ def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, steps=3)
         dt, _ = timed(lambda: ix.hybrid_query(Q, *sp_q, hp_tree), steps)
         out["tree_mode"] = dict(what="reference tree (qdrant_handler.py:305-372), P-mcp limits 100/80/60/40/40/50/30, "
                                      "same index and batch", queries_per_sec=B / dt, ms_per_step=dt * 1e3)
+        # the same step with the fp16 copy nominating the dense candidates (round 2's path; the lists are the same)
+        ix.set_dense_candidates("f16")
+        ix.profile(True)
+        ix.profile_read()
+        dt, r16 = timed(lambda: ix.hybrid_query(Q, *sp_q, hp_h1), steps)
+        p16 = ix.profile_read()["scan_f16"]
+        ix.profile(False)
+        ix.set_dense_candidates("i8")
+        out["fp16_candidates"] = dict(
+            what="the timed step with the dense candidates nominated by the fp16 scan instead of the int8 scan",
+            queries_per_sec=B / dt, ms_per_step=dt * 1e3, same_lists_as_the_timed_step=bool(
+                last_res is not None and torch.equal(r16[0], last_res[0]) and torch.equal(r16[1], last_res[1])),
+            scan=dict(kernel="k_scan8<fp16, v_mfma_f32_16x16x32_f16>", launches=p16["launches"],
+                      avg_launch_ms=p16["ms"] / max(p16["launches"], 1),
+                      achieved_tflops=p16["flops"] / p16["ms"] / 1e9 if p16["ms"] else None, peak_tflops=PEAK_FP16_TFLOPS,
+                      frac=p16["flops"] / p16["ms"] / 1e9 / PEAK_FP16_TFLOPS if p16["ms"] else None))
     runs = []
     for b in (1, 8, 32):
         q = Q[:b].contiguous()
-        for name, fn, key in (("fp16 scan + exact fp32 re-score", lambda: ix.search_dense(q, 10), "scan_f16"),
-                              ("int8 scan (exact)", lambda: ix.search_i8(q, 10), "scan_i8")):
+        for name, fn, key in (("int8 candidate scan + exact fp32 re-score (the dense stage)", lambda: ix.search_dense(q, 10), "scan_cand8"),
+                              ("fp16 candidate scan + exact fp32 re-score", lambda: ix.search_dense(q, 10), "scan_f16"),
+                              ("int8 scan of the 'quantized' vector (exact integer scores)", lambda: ix.search_i8(q, 10), "scan_i8")):
+            ix.set_dense_candidates("f16" if key == "scan_f16" else "i8")
             fn()
             torch.cuda.synchronize()
             ix.profile(True)
@@ -210,9 +295,11 @@ def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, steps=3)
                 gbs = p["bytes"] / p["ms"] / 1e6
                 runs.append(dict(batch=b, stage=name, ms_per_pass=dt * 1e3, scan_ms_per_pass=p["ms"] / 6,   # 1 + 5 calls
                                  scan_gbs=gbs, frac_of_hbm_peak=gbs / PEAK_HBM_GBS, queries_per_sec=b / dt))
+    ix.set_dense_candidates("i8")
     out["dense_knn_small_batch"] = dict(
         what=f"dense kNN top-10 over the same {wl['rows']} x {wl['dim']} corpus, B queries per pass: algorithmic bytes "
-             "(rows * row_bytes + B * row_bytes) / HIP-event time of the scan launches; north-star target >= 0.70",
+             "(rows * row_bytes + B * row_bytes of the copy that is scanned: 1 B per element for the int8 copies, 2 B "
+             "for fp16; SURVEY 8(d)) / HIP-event time of the scan launches; north-star target >= 0.70",
         peak_gbs=PEAK_HBM_GBS, runs=runs)
     # BASELINE config 2 on an index of its own (1M x 384, dense only, B = 256), checked against the C oracle
     c2 = WORKLOADS["cfg2"]
@@ -235,9 +322,57 @@ def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, steps=3)
     return out
 
 
+def cfg4_shard_leg(eng, synth, torch, local, tabs, Q, sp_q, hp, B, sel, dim, check, share_note):
+    """BASELINE config 4 = 100M x 768 row-sharded over 8 GPUs = 12.5M rows per GPU.  One such shard (rank 0's: rows
+    [0, 12.5M) of the same generator, with its postings) on this one GPU: the H1 step every rank would run before the
+    exchange, its lists brute-forced on the host like the main workload's."""
+    rows = 12_500_000
+    out = dict(what="one rank's shard of BASELINE config 4 (100M x 768 over 8 GPUs): 12.5M x 768 + postings on ONE GPU, "
+                    "H1 step at B = 1024 -- the per-rank step before the exchange", rows=rows, batch=B)
+    try:
+        t0 = time.perf_counter()
+        ix = eng.HxIndex(dim, (64, 128, 256), device=local)
+        ix.reserve(rows)
+        ix.synth_fill(rows, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs)
+        ix.finalize()
+        torch.cuda.synchronize()
+        out["build_s"] = round(time.perf_counter() - t0, 2)
+        for _ in range(2):
+            res = ix.hybrid_query(Q, *sp_q, hp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            res = ix.hybrid_query(Q, *sp_q, hp)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        st = ix.stats()
+        out.update(ms_per_step=dt * 1e3, queries_per_sec_per_rank=B / dt,
+                   x8_before_the_exchange=f"{8 * rows} rows at {B / dt:.0f} queries/s if the all-gather of 8 x {B} x 200 keys "
+                                          "hides behind the next batch (distributed.H1Pipeline)",
+                   nnz=st["nnz"], uncertified_queries=st["cand8_uncertified_queries"],
+                   exact_fallback_queries=st["dense_fallback_queries"], sparse_fallback_queries=st["sparse_fallback_queries"],
+                   hbm_gb=(st["bytes_dense_f32"] + st["bytes_dense_f16"] + st["bytes_i8"] + st["bytes_i8_cand"] +
+                           st["bytes_prefix"] + st["bytes_sparse"]) / 1e9)
+        if check:
+            gs, gi = eng.unpack(res[0])
+            res_np = (gs.cpu().numpy(), gi.cpu().numpy(), res[1].cpu().numpy())
+            wl = dict(rows=rows, mode="h1", batch=B)
+            cb = cpu_baseline(wl, sel, dim, tabs, res_np, share_note=share_note)
+            out.update(parity_on_sample=cb["parity_on_sample"], recall_at_10=cb["recall_at_10"], checked=cb["checked"],
+                       cpu_queries_per_sec=cb["value"], sample=cb["sample"])
+        ix.close()
+    except Exception as e:
+        out["error"] = repr(e)[:300]
+    return out
+
+
 def main():
     args = parse()
-    os.environ.setdefault("OMP_NUM_THREADS", str(args.cpu_threads))
+    share, share_note = host_share()
+    if args.cpu_threads > 0:
+        share, share_note = args.cpu_threads, f"--cpu-threads {args.cpu_threads}"
+    os.environ.setdefault("OMP_NUM_THREADS", str(share))
     import torch
     import torch.distributed as dist
     from rag_application_amd import engine as eng, synth
@@ -354,14 +489,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- roofline of the dominant kernel (fp16 MFMA scan), measured with HIP events ------
-    sc = prof["scan_f16"]
+    # ---- roofline of the dominant kernel (the dense stage's candidate scan), measured with HIP events ------
+    use8 = prof["scan_cand8"]["launches"] > 0
+    sc = prof["scan_cand8"] if use8 else prof["scan_f16"]
+    peak_mfma = PEAK_I8_TOPS if use8 else PEAK_FP16_TFLOPS
     roof = None
     if sc["launches"]:
         sec = sc["ms"] / 1e3
         tf = sc["flops"] / sec / 1e12
         gbs = sc["bytes"] / sec / 1e9
-        mfma_bound = (sc["flops"] / (PEAK_FP16_TFLOPS * 1e12)) >= (sc["bytes"] / (PEAK_HBM_GBS * 1e9))
+        mfma_bound = (sc["flops"] / (peak_mfma * 1e12)) >= (sc["bytes"] / (PEAK_HBM_GBS * 1e9))
         # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE pass of this same command (gfx950
         # correction x2, MI355X_MICROARCH.md), kept under profiles/ -- counters cannot be read from
         # inside the timed process.  null when no pass for this configuration is committed.
@@ -372,16 +509,23 @@ def main():
                 tp = json.load(f)
             if tp.get("config") == {"rows": rows, "dim": dim, "batch": B, "n_gpus": 1}:
                 traffic = tp["scan_traffic_gb_per_step"] / max(sc["launches"] / args.steps, 1)
-        roof = dict(kernel="k_scan8<fp16, v_mfma_f32_16x16x32_f16> (256x256 tile)" if B > 128 else "k_scan<fp16> (128-row tiles)",
+        if B > 128:
+            kname = ("k_scan8<int8, v_mfma_i32_16x16x64_i8> (256x256 tile) over the per-row-scaled int8 copy" if use8
+                     else "k_scan8<fp16, v_mfma_f32_16x16x32_f16> (256x256 tile)")
+        else:
+            kname = "k_scan<int8> (128-row tiles)" if use8 else "k_scan<fp16> (128-row tiles)"
+        roof = dict(kernel=kname,
                     bound="mfma" if mfma_bound else "hbm",
-                    achieved=tf if mfma_bound else gbs, peak=PEAK_FP16_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+                    achieved=tf if mfma_bound else gbs, peak=peak_mfma if mfma_bound else PEAK_HBM_GBS,
                     unit="TFLOP/s" if mfma_bound else "GB/s",
-                    frac=(tf / PEAK_FP16_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS), traffic=traffic,
+                    unit_note=("int8 multiply-accumulates counted as 2 ops each, against the dense int8 MFMA peak (2x fp16)"
+                               if use8 else "fp16 MFMA"),
+                    frac=(tf / peak_mfma) if mfma_bound else (gbs / PEAK_HBM_GBS), traffic=traffic,
                     traffic_unit=f"GB per launch, from the committed PMC pass profiles/{PMC_PROFILE} (not measured in this run)",
                     launches=sc["launches"], avg_launch_ms=sc["ms"] / sc["launches"],
                     alg_tflop_per_launch=sc["flops"] / sc["launches"] / 1e12,
                     alg_gb_per_launch=sc["bytes"] / sc["launches"] / 1e9,
-                    other_bound_frac=(gbs / PEAK_HBM_GBS) if mfma_bound else (tf / PEAK_FP16_TFLOPS),
+                    other_bound_frac=(gbs / PEAK_HBM_GBS) if mfma_bound else (tf / peak_mfma),
                     sparse_ms_per_step=prof["sparse"]["ms"] / max(args.steps, 1))
         sp = prof["sparse"]
         if sp["launches"] and sp["ms"] > 0:   # second kernel of the step, HBM-bound by construction
@@ -395,21 +539,27 @@ def main():
     # ---- CPU baseline + parity of the TIMED result (rank 0, N = 1 only) ------------------------------
     cpu = None
     side = None
+    st_main = ix.stats() if rank == 0 else None
     if rank == 0 and world == 1:
+        nq = max(1, min(args.cpu_queries, B))
+        sel = np.arange(0, B, max(B // nq, 1))[:nq]
+        if not args.no_cpu_baseline:      # (before the side measurements: they end with this index freed)
+            gs, gi = eng.unpack(res[0])
+            res_np = (gs.cpu().numpy(), gi.cpu().numpy(), res[1].cpu().numpy())
+            cpu = cpu_baseline(wl, sel, dim, tabs, res_np, share_note=share_note)
         if not args.no_secondary:
             hp_tree = eng.make_params(P, mode=eng.HX_MODE_TREE)
             side = secondary(eng, synth, torch, ix, wl, tabs, Q, (qip_d, qix_d, qv_d) if mode == "h1" else None,
-                             local, hp_tree)
-            side["ingest"] = ingest_leg(eng, torch, local, t_build, rows, ix.stats()["nnz"])
-        if not args.no_cpu_baseline:
-            gs, gi = eng.unpack(res[0])
-            res_np = (gs.cpu().numpy(), gi.cpu().numpy(), res[1].cpu().numpy())
-            nq = max(1, min(args.cpu_queries, B))
-            sel = np.arange(0, B, max(B // nq, 1))[:nq]
-            cpu = cpu_baseline(wl, sel, dim, tabs, res_np)
+                             local, hp_tree, hp, res)
+            side["ingest"] = ingest_leg(eng, synth, torch, local, t_build, rows, st_main["nnz"], tabs)
+            if mode == "h1" and args.workload == "cfg3" and not args.rows:
+                # BASELINE config 4's per-GPU shape on this one GPU: the 10M index is freed first
+                ix.close()
+                side["cfg4_shard"] = cfg4_shard_leg(eng, synth, torch, local, tabs, Q, (qip_d, qix_d, qv_d), hp, B, sel,
+                                                    dim, not args.no_cpu_baseline, share_note)
 
     if rank == 0:
-        st = ix.stats()
+        st = st_main
         line = {
             "metric": "queries/sec, 10M x 768 hybrid dense+BM25 (RRF top-10)"
                       if (args.workload == "cfg3" and rows == WORKLOADS["cfg3"]["rows"] and B == WORKLOADS["cfg3"]["batch"])
@@ -419,19 +569,24 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "rows": rows, "dim": dim, "batch": B, "top_k": 10,
-                       "arithmetic": "dense: fp16 MFMA candidate scan + exact fp32 re-score (certified); sparse: "
-                                     + SPARSE_ARITH,
+                       "arithmetic": "dense: " + (DENSE_ARITH if st["cand8_queries"] else "fp16 MFMA candidate scan + exact fp32 "
+                                                  "re-score (certified)") + "; sparse: " + SPARSE_ARITH,
+                       "dense_candidates": {"kind": "int8" if st["cand8_queries"] else "fp16",
+                                            "queries": st["cand8_queries"], "uncertified_queries": st["cand8_uncertified_queries"],
+                                            "largest_row_quantisation_error": st["cand8_row_error_max"],
+                                            "int8_copy_gb": st["bytes_i8_cand"] / 1e9},
                        "sharding": f"rows/{world}", "nnz_per_shard": st["nnz"],
                        # N > 1: the exchange + fusion of batch i overlap the local stage of batch i + 1
                        "batches_in_flight": 2 if pipe is not None else 1,
-                       "exact_fallback_queries": st["dense_fallback_queries"], "build_s": round(t_build, 2),
+                       "exact_fallback_queries": st["dense_fallback_queries"], "retry_queries": st["retry_queries"],
+                       "sparse_fallback_queries": st["sparse_fallback_queries"], "build_s": round(t_build, 2),
                        **({"sharded_equals_single_index": verified} if verified is not None else {})},
             # recall@10 of the LAST TIMED STEP's lists against the host brute force over the whole corpus
             "recall_at_10": cpu["recall_at_10"] if cpu else None,
             "roofline": roof, "cpu_baseline": cpu, "secondary": side,
         }
         print(json.dumps(line), flush=True)
-    ix.close()
+    ix.close()      # (idempotent: the config 4 leg may have freed it already)
     if world > 1:
         dist.destroy_process_group()
 

@@ -254,15 +254,17 @@ typedef struct hx_stats {
 int hx_get_stats(hx_index* h, hx_stats* out);
 /* HIP-event profile of the hot kernels, measured on the stream they run on.
  * Index 0 = fp16 scan (k_scan<F16>), 1 = int8 scan of the "quantized" stage (k_scan<I8>), 3 = int8 candidate scan of
- * the dense stage (the same kernel over the per-row-scaled copy), 2 = sparse scoring
+ * the dense stage (the same kernel over the per-row-scaled copy), 4 = the ingest kernel (K1/K2: k_prep_rows; bytes =
+ * the raw row read once + every derived copy written once), 5 = spare, 2 = sparse scoring
  * (k_sparse_select: the pass over the inverted index; bytes = 8 per posting of the queries' terms).  flops/bytes are ALGORITHMIC: 2*B*rows*D and rows*row_bytes +
  * B*row_bytes per scan launch.  hx_profile_read drains what was recorded
  * since the last read (it synchronises the recorded events). */
+#define HX_PROF_SLOTS 6
 typedef struct hx_prof {
-  int64_t launches[4];
-  double ms[4];
-  double flops[4];
-  double bytes[4];
+  int64_t launches[HX_PROF_SLOTS];
+  double ms[HX_PROF_SLOTS];
+  double flops[HX_PROF_SLOTS];
+  double bytes[HX_PROF_SLOTS];
 } hx_prof;
 /* Which copy nominates the candidates of the full-vector dense stage: 1 = the per-row-scaled int8 copy (the
  * default; a query its certificate does not cover is re-run on the fp16 copy), 0 = the fp16 copy.  The lists are the

@@ -42,8 +42,8 @@ class HxStats(C.Structure):
 
 
 class HxProf(C.Structure):
-    _fields_ = [("launches", C.c_int64 * 4), ("ms", C.c_double * 4), ("flops", C.c_double * 4),
-                ("bytes", C.c_double * 4)]
+    _fields_ = [("launches", C.c_int64 * 6), ("ms", C.c_double * 6), ("flops", C.c_double * 6),
+                ("bytes", C.c_double * 6)]
 
 
 _P = C.c_void_p

@@ -241,6 +241,35 @@ static void reserve_sparse(hx_index* h, int64_t rows, int64_t nnz) {
   }
 }
 
+struct ProfScope {
+  hx_index* h;
+  hipStream_t st;
+  hx_index::ProfRec rec{};
+  bool on;
+  ProfScope(hx_index* h_, hipStream_t st_, int what, double flops, double bytes, bool enable = true)
+      : h(h_), st(st_), on(h_->prof && enable) {
+    if (!on) return;
+    if (h->prof_pool.empty()) {
+      hipEvent_t a, b;
+      HX_HIP(hipEventCreate(&a));
+      HX_HIP(hipEventCreate(&b));
+      h->prof_pool.emplace_back(a, b);
+    }
+    rec.a = h->prof_pool.back().first;
+    rec.b = h->prof_pool.back().second;
+    h->prof_pool.pop_back();
+    rec.what = what;
+    rec.flops = flops;
+    rec.bytes = bytes;
+    HX_HIP(hipEventRecord(rec.a, st));
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.b, st);
+    h->prof_recs.push_back(rec);
+  }
+};
+
 static void prep_rows_device(hx_index* h, const float* raw_dev, int64_t n, hipStream_t st) {
   PrepRowsArgs a{};
   a.raw = raw_dev;
@@ -261,6 +290,11 @@ static void prep_rows_device(hx_index* h, const float* raw_dev, int64_t n, hipSt
   a.q8s = h->cand8 ? h->q8s + h->n * h->dim_pad8 : nullptr;
   a.q8s_scale = h->cand8 ? h->q8s_scale + h->n : nullptr;
   a.err_max = h->s8_err;
+  // K1/K2 of SURVEY 8(d): the raw row read once, every derived copy written once
+  double per_row = (double)h->dim * 4 + (double)h->dim_pad * 6 + (double)h->dim_pad8 * (h->cand8 ? 2 : 1) + (h->cand8 ? 8 : 4);
+  for (int p = 0; p < h->n_pre; ++p) per_row += (double)h->psize[p] * 4;
+  if (h->n_pre > 0) per_row += (double)h->psize[0] * 2;
+  ProfScope ps(h, st, 4, 0.0, per_row * (double)n);
   launch_prep_rows(a, st);
 }
 
@@ -453,9 +487,12 @@ static int predict_rank(int Lp, double g_eff) {
 // vectors of 768 uniform components, against 1.25e-3 for fp16) asks for more candidates: the L'-th best int8
 // score has to lie a radius below the exact L-th best.
 static int cand8_lprime(int L) {
-  static const int mul = getenv("HX_DEBUG_CAND8_MUL") ? std::max(1, atoi(getenv("HX_DEBUG_CAND8_MUL"))) : 4;
+  // Measured on 10M x 768 (uniform components, radius 0.22 sigma of the score distribution), L = 100: L' = 320
+  // leaves 3 % of the queries uncertified, 400 none of 12,288 (a margin of ~3.8 standard deviations of the gap
+  // between the two order statistics), 450 is ~4.8: an uncertified query costs a whole fp16 scan of its own.
+  static const int mul2 = getenv("HX_DEBUG_CAND8_MUL") ? std::max(2, 2 * atoi(getenv("HX_DEBUG_CAND8_MUL"))) : 9;   // halves
   static const int add = getenv("HX_DEBUG_CAND8_ADD") ? std::max(0, atoi(getenv("HX_DEBUG_CAND8_ADD"))) : 288;
-  return std::min(std::max(mul * L, L + add), std::max(L, CAND_CAP / 4));
+  return std::min(std::max(mul2 * L / 2, L + add), std::max(L, CAND_CAP / 4));
 }
 static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false) {
   static thread_local std::map<std::tuple<int, bool, bool, bool>, Geometry> cache;
@@ -467,13 +504,20 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false) {
   if (cand8) g.Lp = cand8_lprime(L);
   if (safe) g.Lp = std::min(std::max(2 * g.Lp, g.Lp + 256), CAND_CAP / 4);
   int c = next_pow2(std::max(8 * g.Lp, 1024));
-  if (cand8) c = std::max(c, 4096);
+  if (cand8) {
+    static const int cmin = getenv("HX_DEBUG_CAND8_C") ? atoi(getenv("HX_DEBUG_CAND8_C")) : 4096;
+    c = std::max(c, cmin);
+  }
   g.C = safe ? CAND_CAP : std::min(c, CAND_CAP);
   HX_CHECK(g.Lp * 2 <= g.C && g.Lp >= L, "limit too large");
   g.predictive = false;
   g.grow = 2;
   if (!safe) {
-    for (int gr = 64; gr > 2; --gr) {
+    // (int8 candidates, L' = 450: growth 63 / 24 / 16 / 12 / 8 -> 2 / 3 / 3 / 4 / 4 launches per 10M rows, 10.69 /
+    // 10.53 / 10.48 / 10.47 / 10.48 ms per step: the appended volume per launch falls with the growth)
+    static const int gmax8 = getenv("HX_DEBUG_GROW_MAX8") ? std::max(3, atoi(getenv("HX_DEBUG_GROW_MAX8"))) : 16;
+    static const int gmax = getenv("HX_DEBUG_GROW_MAX") ? std::max(3, atoi(getenv("HX_DEBUG_GROW_MAX"))) : 64;
+    for (int gr = std::min(64, cand8 ? gmax8 : gmax); gr > 2; --gr) {
       const int kq = predict_rank(g.Lp, (double)gr);
       if (kq < g.Lp && 1.0 - nb_cdf(kq, 1.0 / gr, g.C - g.Lp) <= PREDICT_EPS) {
         g.grow = gr;
@@ -482,6 +526,9 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false) {
       }
     }
   }
+  if (getenv("HX_DEBUG_GEOMETRY"))
+    fprintf(stderr, "[hx] geometry L=%d approx=%d safe=%d cand8=%d: Lp=%d C=%d grow=%d kq=%d predictive=%d\n", L, (int)approx,
+            (int)safe, (int)cand8, g.Lp, g.C, g.grow, g.predictive ? predict_rank(g.Lp, (double)g.grow) : g.Lp, (int)g.predictive);
   return cache[key] = g;
 }
 
@@ -505,35 +552,6 @@ static void zero_outputs(uint64_t* keys, int* cnt, int B, int L, hipStream_t st)
   HX_HIP(hipMemsetAsync(keys, 0, (size_t)B * L * 8, st));
   HX_HIP(hipMemsetAsync(cnt, 0, (size_t)B * 4, st));
 }
-
-struct ProfScope {
-  hx_index* h;
-  hipStream_t st;
-  hx_index::ProfRec rec{};
-  bool on;
-  ProfScope(hx_index* h_, hipStream_t st_, int what, double flops, double bytes, bool enable = true)
-      : h(h_), st(st_), on(h_->prof && enable) {
-    if (!on) return;
-    if (h->prof_pool.empty()) {
-      hipEvent_t a, b;
-      HX_HIP(hipEventCreate(&a));
-      HX_HIP(hipEventCreate(&b));
-      h->prof_pool.emplace_back(a, b);
-    }
-    rec.a = h->prof_pool.back().first;
-    rec.b = h->prof_pool.back().second;
-    h->prof_pool.pop_back();
-    rec.what = what;
-    rec.flops = flops;
-    rec.bytes = bytes;
-    HX_HIP(hipEventRecord(rec.a, st));
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(rec.b, st);
-    h->prof_recs.push_back(rec);
-  }
-};
 
 // scan all rows with geometric chunks; leaves the best `keep` keys (sorted) in cand
 // int8 scans: `rinv_x` = the per-row factor of the score (f32(dot) * rinv_x[row]) * rinv_q[query], `tm` its tile maxima;
@@ -1451,23 +1469,7 @@ static void add_sparse_host(hx_index* h, const int64_t* indptr, const int32_t* i
   HX_CHECK(nnz >= 0, "negative nnz");
   HX_CHECK(nnz == 0 || (idx && val), "idx/val is NULL");
   HX_CHECK(h->sp_rows <= h->n, "sparse rows are ahead of the dense rows: add the dense rows of the previous batch first");
-  std::vector<int32_t> tmp;
-  float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
-  for (int64_t r = 0; r < n; ++r) {
-    const int64_t b = indptr[r], e = indptr[r + 1];
-    HX_CHECK(e >= b && e <= nnz, "indptr not monotone");
-    tmp.assign(idx + b, idx + e);
-    std::sort(tmp.begin(), tmp.end());
-    for (size_t i = 0; i < tmp.size(); ++i) {
-      HX_CHECK(tmp[i] >= 0, "sparse index out of range [0, 2^31)");
-      HX_CHECK(i == 0 || tmp[i] != tmp[i - 1], "sparse indices must be unique within a vector");
-    }
-    for (int64_t i = b; i < e; ++i) {
-      HX_CHECK(std::fabs(val[i]) <= SPARSE_ABS_MAX, "sparse values must be finite and at most 1e18 in magnitude");
-      lo = std::min(lo, val[i]);
-      hi = std::max(hi, val[i]);
-    }
-  }
+  for (int64_t r = 0; r < n; ++r) HX_CHECK(indptr[r + 1] >= indptr[r] && indptr[r + 1] <= nnz, "indptr not monotone");
   h->set_device();
   HX_CHECK(h->nnz + nnz < 0xFFFFFFFFll, "nnz per shard must stay below 2^32");
   const int64_t pad = h->n - h->sp_rows;      // dense-only rows so far: empty documents
@@ -1479,10 +1481,43 @@ static void add_sparse_host(hx_index* h, const int64_t* indptr, const int32_t* i
     const int64_t zero = 0;
     HX_HIP(hipMemcpy(h->sp_indptr, &zero, 8, hipMemcpyHostToDevice));
   }
+  // The batch goes to the device BEHIND the committed rows and is checked there -- term ids in [0, 2^31) and unique
+  // within a vector (Qdrant rejects duplicates), finite values with |v| <= SPARSE_ABS_MAX -- before the counters move:
+  // a refused batch leaves nothing behind.  (The per-row sort this replaces was the ingest rate: 0.2 s of one host
+  // core per 131072 chunks against 2 ms of kernels.)
   HX_HIP(hipMemcpy(h->sp_indptr + h->sp_rows + 1, ip.data(), ip.size() * 8, hipMemcpyHostToDevice));
+  float lo = 0.f, hi = 0.f;
   if (nnz) {
     HX_HIP(hipMemcpy(h->sp_idx + h->nnz, idx, (size_t)nnz * 4, hipMemcpyHostToDevice));
     HX_HIP(hipMemcpy(h->sp_val + h->nnz, val, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    constexpr int LONG_CAP = 4096;
+    int64_t* long_rows = (int64_t*)h->ws.get(WS_LONG_ROWS, (size_t)LONG_CAP * 8 + 32);
+    int* flags = (int*)(long_rows + LONG_CAP);             // [0] bad bits, [1] rows too long for the wave compare
+    uint32_t* mm = (uint32_t*)(flags + 2);                 // [0..2] min, max (orderable), non-finite count
+    const uint32_t init[5] = {0u, 0u, 0xFFFFFFFFu, 0u, 0u};
+    HX_HIP(hipMemcpy(flags, init, 20, hipMemcpyHostToDevice));
+    const int64_t* rows_ip = h->sp_indptr + h->sp_rows + pad;
+    launch_csr_check(rows_ip, h->sp_idx, n, h->nnz, h->nnz + nnz, flags, nullptr);
+    launch_csr_unique(rows_ip, h->sp_idx, n, flags, long_rows, LONG_CAP, flags + 1, nullptr);
+    launch_minmax_f32(h->sp_val + h->nnz, nnz, (float*)mm, nullptr);
+    uint32_t got[5];
+    HX_HIP(hipMemcpy(got, flags, 20, hipMemcpyDeviceToHost));
+    HX_CHECK((got[0] & 1) == 0, "indptr not monotone");
+    HX_CHECK((got[0] & 2) == 0, "sparse index out of range [0, 2^31)");
+    HX_CHECK((got[0] & 4) == 0, "sparse indices must be unique within a vector");
+    if (got[1] > 0) {          // vectors of more than CSR_UNIQUE_WAVE_MAX terms: sorted here, from the caller's arrays
+      std::vector<int32_t> tmp;
+      for (int64_t r = 0; r < n; ++r) {
+        if (indptr[r + 1] - indptr[r] <= CSR_UNIQUE_WAVE_MAX) continue;
+        tmp.assign(idx + indptr[r], idx + indptr[r + 1]);
+        std::sort(tmp.begin(), tmp.end());
+        HX_CHECK(std::adjacent_find(tmp.begin(), tmp.end()) == tmp.end(), "sparse indices must be unique within a vector");
+      }
+    }
+    HX_CHECK(got[4] == 0, "sparse values must be finite and at most 1e18 in magnitude");
+    lo = orderable_f32(got[2]);
+    hi = orderable_f32(got[3]);
+    HX_CHECK(lo >= -SPARSE_ABS_MAX && hi <= SPARSE_ABS_MAX, "sparse values must be finite and at most 1e18 in magnitude");
     h->sp_wmin = h->sp_have_w ? std::min(h->sp_wmin, lo) : lo;
     h->sp_wmax = h->sp_have_w ? std::max(h->sp_wmax, hi) : hi;
     h->sp_have_w = true;
@@ -1975,7 +2010,7 @@ int hx_profile_read(hx_index* h, hx_prof* out) {
     HX_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
     HX_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-    const int w = r.what;  // 0 f16 scan, 1 i8 scan ("quantized" stage), 2 sparse select, 3 int8 candidate scan of the dense stage
+    const int w = r.what;  // 0 f16 scan, 1 i8 scan ("quantized" stage), 2 sparse select, 3 int8 candidate scan of the dense stage, 4 K1/K2 ingest
     out->launches[w] += 1;
     out->ms[w] += ms;
     out->flops[w] += r.flops;
@@ -2164,7 +2199,7 @@ int hx_load(const char* path, int32_t device, hx_index** out) {
       // [0, 2^31), finite values
       int* bad = (int*)h->ws.get(WS_MISC, 4);
       HX_HIP(hipMemset(bad, 0, 4));
-      launch_csr_check(h->sp_indptr, h->sp_idx, hd.sp_rows, hd.nnz, bad, nullptr);
+      launch_csr_check(h->sp_indptr, h->sp_idx, hd.sp_rows, 0, hd.nnz, bad, nullptr);
       int hbad = 0;
       HX_HIP(hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost));
       HX_CHECK(hbad == 0, "corrupt index file: sparse CSR is inconsistent");

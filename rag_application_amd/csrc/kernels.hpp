@@ -302,10 +302,12 @@ struct SparseRangeArgs {
 void launch_sparse_range(const SparseRangeArgs& a, hipStream_t st);
 // {min, max} of val[0, n) merged into mm[0], mm[1] (fp32, device); mm[2] counts non-finite values
 void launch_minmax_f32(const float* val, int64_t n, float* mm, hipStream_t st);
-// *bad = 1 unless indptr[0] = 0, indptr is monotone up to indptr[n_rows] = nnz and every idx is >= 0
-void launch_csr_check(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int64_t nnz, int* bad, hipStream_t st);
+// n_rows rows of a device CSR whose offsets start at indptr_rows: *bad |= 1 unless indptr_rows[0] = first, the offsets
+// are monotone and indptr_rows[n_rows] = last; *bad |= 2 if an idx in [first, last) is negative
+void launch_csr_check(const int64_t* indptr_rows, const int32_t* idx, int64_t n_rows, int64_t first, int64_t last, int* bad,
+                      hipStream_t st);
 // term ids unique within every row (what hx_add_sparse enforces and k_sparse_rescore's one-ballot-per-term relies
-// on): *bad = 1 on a duplicate.  Rows longer than CSR_UNIQUE_WAVE_MAX terms are not compared on the device: their
+// on): *bad |= 4 on a duplicate.  Rows longer than CSR_UNIQUE_WAVE_MAX terms are not compared on the device: their
 // indices go to long_rows[0, *n_long) (at most long_cap are listed; *n_long keeps counting) for the host to check.
 constexpr int CSR_UNIQUE_WAVE_MAX = 2048;
 void launch_csr_unique(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int* bad, int64_t* long_rows,

@@ -167,8 +167,13 @@ __global__ __launch_bounds__(256) void k_prep_rows(PrepRowsArgs a) {
     a.q8_rinv[row] = n2 > 0 ? (float)(1.0 / sqrt((double)n2)) : 0.0f;
     if (ds8) {
       a.q8s_scale[row] = sx;
+      // (65536 atomics on ONE address per launch serialise at the memory side: only a row that raises the maximum
+      // -- a handful per collection -- issues one)
       const double e = sqrt(err2);
-      if (e <= 3.0e38) atomicMax(a.err_max, __builtin_bit_cast(uint32_t, f32_round_up(e)));   // >= 0: bits order as values
+      if (e <= 3.0e38) {
+        const uint32_t eb = __builtin_bit_cast(uint32_t, f32_round_up(e));   // >= 0: bits order as values
+        if (eb > __builtin_nontemporal_load(a.err_max)) atomicMax(a.err_max, eb);
+      }
     }
   }
 }
@@ -221,7 +226,10 @@ __global__ __launch_bounds__(256) void k_requant_rows(const float* dense, int di
   if (lane == 0) {
     scale[row] = sx;
     const double e = sqrt(err2);
-    if (e <= 3.0e38) atomicMax(err_max, __builtin_bit_cast(uint32_t, f32_round_up(e)));
+    if (e <= 3.0e38) {
+      const uint32_t eb = __builtin_bit_cast(uint32_t, f32_round_up(e));
+      if (eb > __builtin_nontemporal_load(err_max)) atomicMax(err_max, eb);
+    }
   }
 }
 void launch_requant_rows(const float* dense, int dim_pad, int dim_pad8, int64_t n, int8_t* q8s, float* scale,

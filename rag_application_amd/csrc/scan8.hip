@@ -76,10 +76,9 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   constexpr int NT = 32 / TS;          // query tiles of a quadrant
   constexpr int KS = TS == 32 ? 4 : 2; // MFMA k-steps of a k-tile
   constexpr int EPT = TS * TS / 64;    // accumulator registers of one tile
-  constexpr int AUX = (KIND == KIND_I8 ? 2 : 1) * S8_MAXQ * 4;
+  constexpr int AUX = S8_MAXQ * 4;
   __shared__ __attribute__((aligned(1024))) uint8_t lds[8 * S8_HT + AUX];
   float* lds_tau = (float*)(lds + 8 * S8_HT);
-  float* lds_rq = lds_tau + S8_MAXQ;   // I8 only
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,8 +115,17 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   // thresholds (and int8 query scales) of every query -> LDS, +inf for the padding
   const int Bpad = nq * 256;
   for (int q = tid; q < Bpad; q += 512) {
-    lds_tau[q] = q < a.B ? g_tau[q] : __builtin_inff();
-    if constexpr (KIND == KIND_I8) lds_rq[q] = q < a.B ? g_rinv_q[q] : 0.f;
+    float t = q < a.B ? g_tau[q] : __builtin_inff();
+    if constexpr (KIND == KIND_I8) {
+      // threshold of f32(dot) * max row scale: tau / rinv_q pushed down by 2^-20 (the filter may let more columns
+      // through than pass, never fewer); a non-positive threshold passes every column, a zero query scale with a
+      // positive threshold none (all its scores are +0)
+      const float rq = q < a.B ? g_rinv_q[q] : 0.f;
+      if (t <= 0.f) t = -__builtin_inff();
+      else if (!(rq > 0.f)) t = __builtin_inff();
+      else t = (t / rq) * 0.99999905f;
+    }
+    lds_tau[q] = t;
   }
   __syncthreads();
 
@@ -235,6 +243,26 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   auto* g_log = (__attribute__((address_space(1))) u32x4*)a.hitlog +
                 (int64_t)(blockIdx.x * 8 + wave) * a.logcap * S8_ENTRY;
   int wpos = 0;   // entries this wave has logged (scalar)
+  bool pend = false;           // the lower quadrants of the last finished item still wait for their filter
+  int pend_rt = 0, pend_qt = 0;
+  // Thresholds of the item's query columns (lane: column r of tile nt of half hb) and, int8, the row-scale bound of
+  // its corpus tile: fetched once per item at its FIRST k-tile, so that the filter -- which runs in the M segment
+  // and holds the SIMD's matrix slot while it does -- waits for no LDS or scalar load (it did: ~100 cycles of
+  // ds_read latency and ~200 of s_load per quadrant, 13 % of the matrix cycles of a 6-k-tile item).
+  // int8: lds_tau holds tau / rinv_q, rounded down (kernel prologue), and the column bound is f32(max dot) * rxm:
+  // one multiplication, still an upper bound of every score of the column (k_scatter_log computes the exact ones).
+  float tau_it[2][NT];
+  float rxm_it = 0.f;
+  auto fetch_thresholds = [&](int rt, int qt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) tau_it[hb][nt] = lds_tau[qt * 256 + wn * 64 + hb * 32 + nt * TS + r];
+    if constexpr (KIND == KIND_I8) {
+      typedef __attribute__((address_space(4))) const float CF;   // constant address space + uniform index = s_load_dword
+      rxm_it = ((CF*)a.rinv_tile_max)[rt];
+    }
+  };
   auto filter = [&](int rt, int qt, int ha, int hb, acc_t (&c)[MT][NT]) __attribute__((always_inline)) {
     // lane owns query column r of each of the NT tiles and, per row tile, EPT rows:
     //   TS = 32: rows 8*(e>>2) + 4*hh + (e&3);  TS = 16: rows 4*hh + e   (4 consecutive per group)
@@ -255,16 +283,11 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     constexpr int NG = EPT / 4;   // groups of 4 consecutive rows per tile
     // m[nt] >= (an upper bound of) the best score of the lane's column of tile nt
     float tau[NT], m[NT];
-    float rxm = 0.f;   // int8: max row scale of this 256-row tile (a scalar load: lgkmcnt, not vmcnt)
-    if constexpr (KIND == KIND_I8) {
-      // constant address space + uniform index = s_load_dword
-      typedef __attribute__((address_space(4))) const float CF;
-      rxm = ((CF*)a.rinv_tile_max)[rt];
-    }
+    const float rxm = rxm_it;
     bool any = false;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      tau[nt] = lds_tau[q0 + nt * TS];
+      tau[nt] = hb ? tau_it[1][nt] : tau_it[0][nt];
       if constexpr (KIND == KIND_F16) {
         // (v_max3_f32 returns the maximum of the non-NaN operands; garbage rows past the end of
         // the matrix may hold NaNs and are dropped by the row < row_end test anyway)
@@ -286,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 #pragma unroll
           for (int g = 0; g < NG; ++g)
             im = imax3(imax3(im, c[mt][nt][4 * g], c[mt][nt][4 * g + 1]), c[mt][nt][4 * g + 2], c[mt][nt][4 * g + 3]);
-        m[nt] = im > 0 ? ((float)im * rxm) * lds_rq[q0 + nt * TS] : 0.f;
+        m[nt] = im > 0 ? (float)im * rxm : 0.f;
       }
       any |= (m[nt] >= tau[nt]);
     }
@@ -436,6 +459,13 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   // 4T+5 may be in flight), the wait of Y retires g <= 4T+6 (only 4T+7 in flight), each ahead
   // of the barrier before the reading phase.  WAR: slot(g) is restaged by g+8 in the M segment
   // of the phase after its last read, i.e. behind one more barrier than the reads.
+#ifndef HX_S8_FILTER_SPLIT
+#define HX_S8_FILTER_SPLIT 0  // 1: the upper quadrants in phase Y of the last k-tile, the lower ones in the next phase X
+#endif                        //    (spills: the Y site has the B fragments live); 0: the whole tile in the next phase X
+#ifndef HX_S8_FILTER_IN_M
+#define HX_S8_FILTER_IN_M 1   // 1: the filter behind each quadrant's MFMAs, inside the M segment; 0: deferred to the next L
+                              //    segments (tried in round 3: hipcc then spills 36-380 bytes per lane INSIDE the k-loop, behind vmcnt(0))
+#endif
 #ifndef HX_S8_LDMA
 #define HX_S8_LDMA 1   // where the four global_load_lds of a phase are issued: 0 between the MFMAs of its M segment (round 1),
 #endif                 // 1 in its L segment -- by the wave that is NOT on the matrix pipe -- 2 half and half
@@ -453,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     stage1(BASE, KOFF, OFF, SLOT, 1);                                           \
     __builtin_amdgcn_sched_barrier(0);                                          \
   }                                                                             \
-  if (__builtin_expect(last, 0)) filter(rt, qt, HA, HB, ACC);
+  if (HX_S8_FILTER_IN_M && __builtin_expect(last, 0)) filter(rt, qt, HA, HB, ACC);
 #define S8_L_END(N)                                                             \
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                      \
   __builtin_amdgcn_sched_barrier(0);                                            \
@@ -465,18 +495,36 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   __builtin_amdgcn_sched_barrier(0);                                            \
   __builtin_amdgcn_s_barrier();                                                 \
   __builtin_amdgcn_sched_barrier(0);
+  // The threshold filter of a finished tile runs in the L segments that FOLLOW its last MFMAs, not behind them in the
+  // M segment: there this wave would hold the SIMD's matrix slot without using it (its partner is in its L segment,
+  // behind the barrier) -- ~50 VALU instructions per quadrant, four quadrants per tile: 6.5 % of the matrix cycles of
+  // a 12-k-tile item (fp16, dim 768) and 13 % of a 6-k-tile one (int8).  C00, C01 are complete after phase X of the
+  // last k-tile and are filtered in its phase Y; C11, C10 are complete after phase Y and are filtered in phase X of
+  // the NEXT k-tile (the first of the next item, which overwrites them in ITS phase Y only), or after the loop.
   auto ktile = [&](auto par_c, auto first_c) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr bool FIRST = decltype(first_c)::value;
     constexpr int S0 = 4 * PAR, N0 = 4 * (1 - PAR);
     const bool last = (c_kt == KT - 1);
     int rt = 0, qt = 0;
-    if (last) {
+    if (FIRST || last) {
       const int d = __builtin_amdgcn_readfirstlane(cj / nq);
       rt = phys_tile(d * 8 + xcd);
       qt = cj - d * nq;
     }
-    // phase X
+    if (FIRST) fetch_thresholds(rt, qt);
+    // phase X  (the filter comes first: the fragment registers of the previous phase are dead, the new ones not yet
+    // loaded -- placed behind the reads it pushed the kernel over its 256 VGPRs)
+    if (!HX_S8_FILTER_IN_M && FIRST && __builtin_expect(pend, 1)) {     // the previous item's tile
+#if HX_S8_FILTER_SPLIT == 0
+      filter(pend_rt, pend_qt, 0, 0, acc[0][0]);
+      filter(pend_rt, pend_qt, 0, 1, acc[0][1]);
+#endif
+      filter(pend_rt, pend_qt, 1, 1, acc[1][1]);
+      filter(pend_rt, pend_qt, 1, 0, acc[1][0]);
+      pend = false;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     read_a(S0 + 0);
     read_b(S0 + 1, bA);
     read_b(S0 + 2, bB);
@@ -492,6 +540,13 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     S8_QUAD(acc[0][1], bB, 0, 1, c1.a, c1.koff, offA[1], N0 + 3, HX_S8_LDMA != 1)
     S8_M_END()
     // phase Y
+#if HX_S8_FILTER_SPLIT
+    if (!HX_S8_FILTER_IN_M && __builtin_expect(last, 0)) {              // this item's upper quadrants
+      filter(rt, qt, 0, 0, acc[0][0]);
+      filter(rt, qt, 0, 1, acc[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     read_a(S0 + 3);
     if (HX_S8_LDMA) {      // (6 pieces in flight: g = 4T+7 .. 4T+9)
       __builtin_amdgcn_sched_barrier(0);
@@ -502,6 +557,11 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     S8_QUAD(acc[1][1], bB, 1, 1, c2.a, c2.koff, offA[0], S0 + 0, HX_S8_LDMA == 0)
     S8_QUAD(acc[1][0], bA, 1, 0, c2.q, c2.koff, offB[0], S0 + 1, HX_S8_LDMA == 0)
     S8_M_END()
+    if (!HX_S8_FILTER_IN_M && last) {
+      pend = true;
+      pend_rt = rt;
+      pend_qt = qt;
+    }
 
     c1 = c2;
     advance(c2);
@@ -525,6 +585,16 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     ktile_any(std::integral_constant<int, 1>{});
   }
   if (T < total_T) ktile_any(std::integral_constant<int, 0>{});
+#if HX_S8_PH != 4
+  if (!HX_S8_FILTER_IN_M && pend) {                  // the last item's tile
+#if HX_S8_FILTER_SPLIT == 0
+    filter(pend_rt, pend_qt, 0, 0, acc[0][0]);
+    filter(pend_rt, pend_qt, 0, 1, acc[0][1]);
+#endif
+    filter(pend_rt, pend_qt, 1, 1, acc[1][1]);
+    filter(pend_rt, pend_qt, 1, 0, acc[1][0]);
+  }
+#endif
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the never-read tail loads
   if (wm == 0) __builtin_amdgcn_s_barrier();

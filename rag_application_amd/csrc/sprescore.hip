@@ -382,19 +382,22 @@ void launch_minmax_f32(const float* val, int64_t n, float* mm, hipStream_t st) {
   HX_HIP(hipGetLastError());
 }
 
-// a loaded CSR (hx_load): indptr[0] = 0, monotone, indptr[n] = nnz; idx >= 0
-__global__ void k_csr_check(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int64_t nnz, int* bad) {
+// rows of a CSR on the device (hx_load: all of them; hx_add_sparse: the batch being added, before it is committed):
+// indptr_rows[0] = first, monotone, indptr_rows[n_rows] = last; idx[first .. last) >= 0.  *bad |= 1 (offsets) | 2 (ids)
+__global__ void k_csr_check(const int64_t* indptr_rows, const int32_t* idx, int64_t n_rows, int64_t first, int64_t last,
+                            int* bad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool b = false;
-  if (i < n_rows) b |= indptr[i] > indptr[i + 1] || indptr[i] < 0 || indptr[i + 1] > nnz;
-  if (i == 0) b |= indptr[0] != 0 || indptr[n_rows] != nnz;
-  if (i < nnz) b |= idx[i] < 0;
-  if (b) *bad = 1;
+  int b = 0;
+  if (i < n_rows) b |= (indptr_rows[i] > indptr_rows[i + 1] || indptr_rows[i] < first || indptr_rows[i + 1] > last) ? 1 : 0;
+  if (i == 0) b |= (indptr_rows[0] != first || indptr_rows[n_rows] != last) ? 1 : 0;
+  if (i < last - first) b |= idx[first + i] < 0 ? 2 : 0;
+  if (b) atomicOr(bad, b);
 }
-void launch_csr_check(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int64_t nnz, int* bad, hipStream_t st) {
-  const int64_t m = n_rows > nnz ? n_rows : nnz;
+void launch_csr_check(const int64_t* indptr_rows, const int32_t* idx, int64_t n_rows, int64_t first, int64_t last, int* bad,
+                      hipStream_t st) {
+  const int64_t m = n_rows > last - first ? n_rows : last - first;
   if (m <= 0) return;
-  hipLaunchKernelGGL(k_csr_check, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, indptr, idx, n_rows, nnz, bad);
+  hipLaunchKernelGGL(k_csr_check, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, indptr_rows, idx, n_rows, first, last, bad);
   HX_HIP(hipGetLastError());
 }
 
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void k_csr_unique(const int64_t* indptr, const
       }
     }
   }
-  if (__ballot(dup) && lane == 0) *bad = 1;
+  if (__ballot(dup) && lane == 0) atomicOr(bad, 4);
 }
 void launch_csr_unique(const int64_t* indptr, const int32_t* idx, int64_t n_rows, int* bad, int64_t* long_rows,
                        int long_cap, int* n_long, hipStream_t st) {

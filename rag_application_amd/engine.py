@@ -176,7 +176,7 @@ class HxIndex:
     def profile_read(self) -> dict:
         p = HxProf()
         check(_lib.lib().hx_profile_read(self._h, C.byref(p)))
-        names = ("scan_f16", "scan_i8", "sparse", "scan_cand8")
+        names = ("scan_f16", "scan_i8", "sparse", "scan_cand8", "prep_rows")
         return {n: dict(launches=p.launches[i], ms=p.ms[i], flops=p.flops[i], bytes=p.bytes[i])
                 for i, n in enumerate(names)}
 

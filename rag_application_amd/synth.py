@@ -73,3 +73,25 @@ def sparse_queries(seed: int, q0: int, n: int, tabs=None):
         val.append(bm25_weight(tf, T)[o])
         indptr.append(indptr[-1] + len(r))
     return (np.asarray(indptr, dtype=np.int64), np.concatenate(idx), np.concatenate(val))
+
+
+def ingest_batch(seed: int, n: int, dim: int, tabs=None):
+    """A host-side ingest batch of the bench's shape for timing `store_document_vectors`' hand-off (bench.py, config
+    5): n fp32 rows uniform in [-1, 1) and a sparse CSR drawn like the corpus (document lengths from the lognormal
+    table, tokens from the Zipf CDF, equal tokens merged into tf, BM25 tf weights, term id = rank * 0x9E3779B1 mod
+    2^31) -- the same distributions as `hx_synth_fill`, vectorised, NOT the same random stream (nothing is compared
+    against it).  Returns (dense [n x dim] f32, indptr int64, idx int32, val f32)."""
+    cdf, lens = tabs or tables()
+    rng = np.random.default_rng(seed)
+    dense = rng.random((n, dim), dtype=np.float32) * np.float32(2.0) - np.float32(1.0)
+    L = lens[rng.integers(0, 256, n)].astype(np.int64)
+    rows = np.repeat(np.arange(n, dtype=np.int64), L)
+    u = rng.integers(0, 1 << 32, rows.size, dtype=np.uint64).astype(np.uint32)
+    rank = np.minimum(np.searchsorted(cdf, u, side="right"), V - 1).astype(np.int64)
+    key, tf = np.unique((rows << np.int64(20)) | rank, return_counts=True)      # sorted by row, then rank
+    r = key >> np.int64(20)
+    idx = (((key & np.int64((1 << 20) - 1)).astype(np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0x7FFFFFFF)).astype(np.int32)
+    val = bm25_weight(tf, L[r])
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(r, minlength=n), out=indptr[1:])
+    return dense, indptr, idx, val

@@ -25,7 +25,8 @@ P = dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=
 hp = eng.make_params(P, mode=eng.HX_MODE_H1)
 out = {}
 ref = None
-for kind in ("i8", "f16", "i8"):
+kinds = ("i8",) if os.environ.get("AB_ONLY") == "i8" else ("i8", "f16", "i8")
+for kind in kinds:
     ix.set_dense_candidates(kind)
     for _ in range(2):
         r = ix.hybrid_query(Q, *sp, hp)
@@ -55,7 +56,7 @@ for kind in ("i8", "f16", "i8"):
     out[kind + ("_again" if kind in out else "")] = d
     print(kind, json.dumps(d), flush=True)
 # dense-only small batches: the bandwidth-bound side
-for b in (1, 8, 32):
+for b in (() if os.environ.get("AB_ONLY") else (1, 8, 32)):
     q = Q[:b].contiguous()
     for kind in ("i8", "f16"):
         ix.set_dense_candidates(kind)
