@@ -599,9 +599,26 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   if (bn == 256) {   // per-wave append logs of the 256 x 256 kernel (scan8.hip)
     // a wave logs about (appended per query) * B / SCAN8_WAVES entries per launch; a full log only
     // flags its queries for the retry
-    const double per_query = (g.predictive ? predict_rank(g.Lp, (double)g.grow) : g.Lp) * (g.grow - 1.0);
-    const int want = next_pow2((int)std::min(1e9, 3.0 * per_query * B / SCAN8_WAVES) + 1);
-    logcap = std::min(h->scan_logcap, std::max(256, want));
+    // Planned per launch: the chunk [r0, r1) appends about rank * (r1 / r0 - 1) rows per query (rank = the rank whose
+    // score is its threshold) and its items run on min(SCAN8_WAVES, 8 waves per 256 x 256 tile) waves -- a SMALL
+    // collection has few tiles, so few waves share the same number of appends (15000 rows, B = 130: 43 tiles, and
+    // a capacity planned for 2048 waves overflowed for half the queries).  Three times the mean, the largest launch.
+    double want = 0.0;
+    {
+      const int64_t tiles_all = (h->n + 255) / 256 * 256;
+      int64_t p0 = 0, p1 = std::min<int64_t>(tiles_all, g.C);
+      while (p1 < tiles_all) {
+        const int64_t nx = std::min<int64_t>(tiles_all, std::min<int64_t>(p1 * g.grow, p1 + (1ll << 27)));
+        const double growth = (double)nx / (double)p1;
+        const double rank = g.predictive ? predict_rank(g.Lp, growth) : g.Lp;
+        const double waves = std::min<double>(SCAN8_WAVES, 8.0 * (double)((nx - p1 + 255) / 256) * (double)(round_up(B, 256) / 256));
+        want = std::max(want, 3.0 * rank * (growth - 1.0) * (double)B / waves + 64.0);
+        p0 = p1;
+        p1 = nx;
+      }
+      (void)p0;
+    }
+    logcap = std::min(h->scan_logcap, std::max(256, next_pow2((int)std::min(1e9, want) + 1)));
     hitlog = (uint4*)h->ws.get(WS_HITLOG, (size_t)SCAN8_WAVES * logcap * SCAN8_ENTRY * sizeof(uint4));
     hitcnt = (int*)h->ws.get(WS_HITCNT, (size_t)SCAN8_WAVES * 4);
   }
