@@ -47,15 +47,111 @@ __global__ void k_make_pairs(const int64_t* indptr, const int32_t* idx, const fl
   }
 }
 
+// ---- bank-spread order of a (term, segment) run ---------------------------------------------------------------------
+// The select pass (sparse2.hip) takes a run in chunks of 128 postings, lane l of a wave the postings 2l and 2l + 1 of
+// the chunk, and adds them to LDS with two ds_add_u32 (and harvests them with two ds_and_rtn_b32).  A 32-bit LDS
+// instruction is served in two groups of 32 lanes, bank = word mod 32 = document mod 32: so positions {64 b + 2 i} and
+// {64 b + 2 i + 1}, i < 32, of a run are one group each, and every further posting of a group on a bank already taken
+// costs an LDS cycle (measured in round 2: 60 % of the LDS cycles of the pass were such conflicts -- 32 random banks
+// out of 32 put 3.4 on the fullest).  The integer pass does not care about the order inside a run (sums commute, a
+// document appears once per run), the exact pass reads the document-major CSR.  So the build deals a run's postings
+// into groups by bank: posting number k (in document order) of bank b goes to "tier" k; tiers in order, banks
+// ascending inside a tier, is a sequence whose every aligned 32 hold distinct banks as long as the tiers are full
+// (k < the rarest bank's count) and at most two per bank after that.  Group g of the sequence takes the positions
+// of group g: the even, then the odd positions of block g / 2; the last, partial block is split in halves.
+__device__ __forceinline__ uint2 sp_encode(uint64_t p, uint32_t seg_docs) {
+  // first word: where the document's 16-bit accumulator lives in the select pass's LDS (sparse2.hip: sp_word) --
+  // byte offset of its 32-bit word (document mod seg_docs/2, times 4) | shift of its half (0 / 16) << 24
+  const uint32_t d = (uint32_t)(p >> 32) % seg_docs, words = seg_docs >> 1;
+  return make_uint2(((d & (words - 1)) << 2) | (d >= words ? 16u << 24 : 0u), (uint32_t)p);
+}
 // sorted payloads -> postings {accumulator place of the document inside its segment, weight bits}
 __global__ void k_make_postings(const uint64_t* pay, int64_t nnz, uint32_t seg_docs, uint2* post) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
-  const uint64_t p = pay[i];
-  // first word: where the document's 16-bit accumulator lives in the select pass's LDS (sparse2.hip: sp_word) --
-  // byte offset of its 32-bit word (document mod seg_docs/2, times 4) | shift of its half (0 / 16) << 24
-  const uint32_t d = (uint32_t)(p >> 32) % seg_docs, words = seg_docs >> 1;
-  post[i] = make_uint2(((d & (words - 1)) << 2) | (d >= words ? 16u << 24 : 0u), (uint32_t)p);
+  post[i] = sp_encode(pay[i], seg_docs);
+}
+
+// one wave: run [b, e) of `pay` (document order) -> post[b .. e) in bank-spread order
+__device__ __forceinline__ void sp_spread_run(const uint64_t* pay, uint2* post, uint64_t b, uint64_t e, uint32_t seg_docs,
+                                              int lane) {
+  const uint32_t len = (uint32_t)(e - b);
+  if (len <= 2) {                                   // one posting per group at most
+    if ((uint32_t)lane < len) post[b + lane] = sp_encode(pay[b + lane], seg_docs);
+    return;
+  }
+  // pass A: postings per bank (wave-uniform counters: popcounts of ballots)
+  uint32_t cnt[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) cnt[k] = 0;
+  for (uint32_t c = 0; c < len; c += 64) {
+    const bool in = c + lane < len;
+    const uint32_t bank = in ? (uint32_t)(pay[b + c + lane] >> 32) & 31u : 0xFFu;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) cnt[k] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(bank == (uint32_t)k));
+  }
+  // pass B: number of a posting inside its bank -> place in the tier sequence -> position of its group
+  const uint32_t full = len >> 6, tail = len & 63u, half = (tail + 1) >> 1;
+  uint32_t seen[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) seen[k] = 0;
+  const uint64_t below = (1ull << lane) - 1ull;
+  for (uint32_t c = 0; c < len; c += 64) {
+    const bool in = c + lane < len;
+    const uint64_t p = in ? pay[b + c + lane] : 0ull;
+    const uint32_t bank = in ? (uint32_t)(p >> 32) & 31u : 0xFFu;
+    uint32_t occ = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const uint64_t m = __builtin_amdgcn_ballot_w64(bank == (uint32_t)k);
+      if (bank == (uint32_t)k) occ = seen[k] + (uint32_t)__builtin_popcountll(m & below);
+      seen[k] += (uint32_t)__builtin_popcountll(m);
+    }
+    uint32_t i = 0;                                 // place in the sequence: the tiers before, the lower banks of this tier
+#pragma unroll
+    for (int k = 0; k < 32; ++k) i += (cnt[k] < occ ? cnt[k] : occ) + (((uint32_t)k < bank && cnt[k] > occ) ? 1u : 0u);
+    const uint32_t blk = i >> 6, r = i & 63u;
+    uint32_t pos;
+    if (blk < full) pos = (blk << 6) + ((r & 31u) << 1) + (r >> 5);
+    else pos = (blk << 6) + (r < half ? (r << 1) : (((r - half) << 1) + 1u));
+    if (in) post[b + pos] = sp_encode(p, seg_docs);
+  }
+}
+
+// terms of at most SPREAD_HEAVY postings: one wave per term, run by run (a run's end comes from the offset table);
+// the others are listed for k_spread_heavy
+constexpr uint32_t SPREAD_HEAVY = 32768;
+__global__ __launch_bounds__(256) void k_spread_light(const uint64_t* pay, const uint64_t* run_off, const uint32_t* run_len,
+                                                      const uint32_t* ptr, int64_t n_live, int nseg, uint32_t seg_docs,
+                                                      uint2* post, uint32_t* heavy, uint32_t* n_heavy) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_live) return;
+  const uint32_t cnt = run_len[t];
+  if (cnt > SPREAD_HEAVY) {
+    if (lane == 0) heavy[atomicAdd(n_heavy, 1u)] = (uint32_t)t;
+    return;
+  }
+  const uint64_t b0 = run_off[t], e0 = b0 + cnt;
+  const uint32_t* row = ptr + t * (int64_t)(nseg + 1);
+  uint64_t cur = b0;
+  while (cur < e0) {                                // wave-uniform
+    const uint32_t seg = (uint32_t)(pay[cur] >> 32) / seg_docs;
+    const uint64_t end = row[seg + 1];
+    sp_spread_run(pay, post, cur, end, seg_docs, lane);
+    cur = end;
+  }
+}
+// one workgroup per (heavy term, 16 segments): a wave per run
+__global__ __launch_bounds__(256) void k_spread_heavy(const uint64_t* pay, const uint32_t* ptr, const uint32_t* heavy,
+                                                      int nseg, uint32_t seg_docs, uint2* post) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t t = heavy[blockIdx.x];
+  const uint32_t* row = ptr + t * (int64_t)(nseg + 1);
+  for (int s = blockIdx.y * 16 + w; s < nseg && s < (int)blockIdx.y * 16 + 16; s += 4) {
+    const uint64_t b = row[s], e = row[s + 1];
+    if (e > b) sp_spread_run(pay, post, b, e, seg_docs, lane);
+  }
 }
 
 // one workgroup per live term: ptr[t][s] = first posting of the term's run [b, e) whose document
@@ -139,9 +235,34 @@ void build_sparse_index(const int64_t* indptr, const int32_t* idx, const float* 
   HX_HIP(hipMemcpyAsync(out->uterms, uterms.p, (size_t)n_live * 4, hipMemcpyDeviceToDevice, st));
   HX_HIP(hipMalloc((void**)&out->post, (size_t)(nnz + 2) * sizeof(uint2)));   // + padding: sparse2.hip loads pairs
   HX_HIP(hipMemsetAsync(out->post + nnz, 0, 2 * sizeof(uint2), st));
-  hipLaunchKernelGGL(k_make_postings, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p_out.as<uint64_t>(),
-                     nnz, (uint32_t)seg_docs, out->post);
-  HX_HIP(hipGetLastError());
+  // Measured (round 3, 10M x 1e9 postings, B = 1024; profiles/r03_pmc_sparse_select.json): the bank-spread order takes
+  // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the select pass from 0.60 to 0.33 -- and its time from 2.040 to 2.035 ms:
+  // the LDS pipe is active for 11 % of the kernel's cycles either way, the conflicts were never what the waves wait
+  // for.  It costs 90 ms per 1e9 postings at build time, so it is OFF unless asked for (HX_SP_SPREAD=1).
+  const char* sp_env = getenv("HX_SP_SPREAD");
+  const bool spread = sp_env && atoi(sp_env) != 0;
+  if (!spread) {
+    hipLaunchKernelGGL(k_make_postings, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, p_out.as<uint64_t>(),
+                       nnz, (uint32_t)seg_docs, out->post);
+    HX_HIP(hipGetLastError());
+  } else {
+    // every posting belongs to exactly one (term, segment) run: the two kernels write all of `post`
+    DevBuf heavy((size_t)(nnz / SPREAD_HEAVY + 2) * 4);                      // a heavy term holds > SPREAD_HEAVY postings
+    uint32_t* n_heavy = heavy.as<uint32_t>();                                 // [0] the count, then the list
+    HX_HIP(hipMemsetAsync(n_heavy, 0, 4, st));
+    hipLaunchKernelGGL(k_spread_light, dim3((unsigned)((n_live + 3) / 4)), dim3(256), 0, st, p_out.as<uint64_t>(),
+                       offs.as<uint64_t>(), counts.as<uint32_t>(), out->ptr, (int64_t)n_live, (int)nseg, (uint32_t)seg_docs,
+                       out->post, n_heavy + 1, n_heavy);
+    HX_HIP(hipGetLastError());
+    uint32_t nh = 0;
+    HX_HIP(hipMemcpyAsync(&nh, n_heavy, 4, hipMemcpyDeviceToHost, st));
+    HX_HIP(hipStreamSynchronize(st));
+    if (nh) {
+      hipLaunchKernelGGL(k_spread_heavy, dim3(nh, (unsigned)((nseg + 15) / 16)), dim3(256), 0, st, p_out.as<uint64_t>(),
+                         out->ptr, n_heavy + 1, (int)nseg, (uint32_t)seg_docs, out->post);
+      HX_HIP(hipGetLastError());
+    }
+  }
   HX_HIP(hipStreamSynchronize(st));
   out->n_live = (int64_t)n_live;
   out->ptr_entries = ptr_entries;

@@ -1,12 +1,16 @@
-# PMC passes of the sparse stage alone (scripts/sp_only.py).  usage: bash scripts/sp_pmc.sh <tag> [rows]
-set -e
+# LDS bank-conflict counters of the sparse select pass on the bench workload
+# usage (GPU box): bash scripts/sp_pmc.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-V=${1:-sp}
-N=${2:-10000000}
-for G in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SMEM"; do
-  T=$(echo $G | cut -d' ' -f1)
-  timeout -k 10 300 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sp_$V/$T -o x -- python $R/scripts/sp_only.py $N > $R/gpurun_out/pmc_sp_${V}_$T.log 2>&1
-  echo "pmc $T done"
-done
-python $R/scripts/pmc_sum.py $R/gpurun_out/pmc_sp_$V k_sparse_select
+V=${1:-r03}
+timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sp_$V -o x -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/pmc_sp_$V.log 2>&1
+python - <<PY
+import csv, collections
+agg = collections.OrderedDict()
+for r in csv.DictReader(open("$R/gpurun_out/pmc_sp_$V/x_counter_collection.csv")):
+    if "k_sparse_select" not in r["Kernel_Name"]: continue
+    e = agg.setdefault(int(r["Dispatch_Id"]), {"ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6})
+    e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+for d, e in agg.items():
+    print(d, {k: (round(v, 3) if k == "ms" else v) for k, v in e.items()}, "conflict/active", round(e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"], 3))
+PY

@@ -1031,11 +1031,15 @@ def test_save_load_round_trip(eng, torch_mod, synth_tables, tmp_path):
     ld.close()
 
 
-@pytest.mark.parametrize("seg_docs", [32768, 65536])
+@pytest.mark.parametrize("seg_docs", [32768, 65536, -65536])
 def test_sparse_both_segment_sizes(eng, torch_mod, synth_tables, monkeypatch, seg_docs):
     """The synthetic Zipf corpus through either sparse build: 150k documents (a partial last segment in both),
-    300 queries, top-100."""
+    300 queries, top-100.  Negative: the same with the bank-spread posting order (HX_SP_SPREAD=1: every (term,
+    segment) run permuted for the select pass's LDS banks) -- the lists must not change."""
     from oracle import c_oracle as CO
+    if seg_docs < 0:
+        seg_docs = -seg_docs
+        monkeypatch.setenv("HX_SP_SPREAD", "1")
     monkeypatch.setenv("HX_DEBUG_SEG_DOCS", str(seg_docs))
     n, B = 150000, 300
     ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
