@@ -463,7 +463,8 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 #define HX_S8_FILTER_SPLIT 0  // 1: the upper quadrants in phase Y of the last k-tile, the lower ones in the next phase X
 #endif                        //    (spills: the Y site has the B fragments live); 0: the whole tile in the next phase X
 #ifndef HX_S8_FILTER_IN_M
-#define HX_S8_FILTER_IN_M 1   // 1: the filter behind each quadrant's MFMAs, inside the M segment; 0: deferred to the next L
+#define HX_S8_FILTER_IN_M 1   // 1: the filter behind each quadrant's MFMAs, inside the M segment; 2: both quadrants' filters behind
+                              //    the phase's last MFMA (measured: 7.55 ms per step's scans against 7.39-7.48 for 1); 0: deferred to the next L
                               //    segments (tried in round 3: hipcc then spills 36-380 bytes per lane INSIDE the k-loop, behind vmcnt(0))
 #endif
 #ifndef HX_S8_LDMA
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     stage1(BASE, KOFF, OFF, SLOT, 1);                                           \
     __builtin_amdgcn_sched_barrier(0);                                          \
   }                                                                             \
-  if (HX_S8_FILTER_IN_M && __builtin_expect(last, 0)) filter(rt, qt, HA, HB, ACC);
+  if (HX_S8_FILTER_IN_M == 1 && __builtin_expect(last, 0)) filter(rt, qt, HA, HB, ACC);
 #define S8_L_END(N)                                                             \
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                      \
   __builtin_amdgcn_sched_barrier(0);                                            \
@@ -538,6 +539,10 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     S8_L_END(HX_S8_LDMA == 1 ? 8 : (HX_S8_LDMA == 2 ? 6 : 4))
     S8_QUAD(acc[0][0], bA, 0, 0, c1.q, c1.koff, offB[1], N0 + 2, HX_S8_LDMA == 0)
     S8_QUAD(acc[0][1], bB, 0, 1, c1.a, c1.koff, offA[1], N0 + 3, HX_S8_LDMA != 1)
+    if (HX_S8_FILTER_IN_M == 2 && __builtin_expect(last, 0)) {   // both quadrants behind the phase's last MFMA: the first
+      filter(rt, qt, 0, 0, acc[0][0]);                           // one's results are long there, its VALU work runs under
+      filter(rt, qt, 0, 1, acc[0][1]);                           // the second one's MFMAs still in the pipe
+    }
     S8_M_END()
     // phase Y
 #if HX_S8_FILTER_SPLIT
@@ -556,6 +561,10 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     S8_L_END(HX_S8_LDMA ? 6 : 2)
     S8_QUAD(acc[1][1], bB, 1, 1, c2.a, c2.koff, offA[0], S0 + 0, HX_S8_LDMA == 0)
     S8_QUAD(acc[1][0], bA, 1, 0, c2.q, c2.koff, offB[0], S0 + 1, HX_S8_LDMA == 0)
+    if (HX_S8_FILTER_IN_M == 2 && __builtin_expect(last, 0)) {
+      filter(rt, qt, 1, 1, acc[1][1]);
+      filter(rt, qt, 1, 0, acc[1][0]);
+    }
     S8_M_END()
     if (!HX_S8_FILTER_IN_M && last) {
       pend = true;

@@ -39,9 +39,19 @@ class ModelType(Enum):         # app/core/models/model_type.py:3-9
 
 
 class LocalHFEncoder:
-    """tokenizer(padding=True) -> encoder -> last_hidden_state.mean(dim=1) on the GPU
-    (huggingface.py:165-170), plus the reference's "reranker" (mean-pooled query . docs,
-    argsort descending, :172-189)."""
+    """The reference's HuggingFace client for this path, restated as it is written
+    (app/core/models/huggingface/huggingface.py:165-189), on PyTorch-ROCm from a LOCAL checkpoint:
+
+    embed_text (:165-170)   tokenizer(texts, padding=True) -- NO truncation: a text longer than the model's
+        position table fails inside the model, as upstream (EmbeddingHandler.encode_dense then returns [],
+        embedding_handler.py:96-98) -- then `last_hidden_state.mean(dim=1)`: the mean runs over EVERY position of the
+        padded batch, padding included (no attention-mask weighting), and nothing is normalised.
+    rerank_documents (:172-189)   not ColBERT late interaction despite the name: the query alone and the documents
+        (padded together) go through the same unmasked mean pooling, scores = q . D^T, `argsort` descending.  Its
+        truncation branch is kept as written: it tests `len(doc_tokens) > 8000`, and `len` of a tokenizer's
+        BatchEncoding is its number of KEYS (input_ids, attention_mask, ...), so the branch never runs for a real
+        tokenizer; if it does, every document is cut to `max_tokens - 5` CHARACTERS plus "....." and tokenized again.
+        Named quirk, not fixed: reference parity."""
 
     def __init__(self, model_path: str, device: Optional[str] = None):
         import torch
@@ -51,23 +61,27 @@ class LocalHFEncoder:
         self.tokenizer = AutoTokenizer.from_pretrained(model_path, local_files_only=True)
         self.model = AutoModel.from_pretrained(model_path, local_files_only=True).to(self.device).eval()
 
-    def _pool(self, texts: List[str]):
-        torch = self.torch
-        inputs = self.tokenizer(texts, return_tensors="pt", padding=True, truncation=True).to(self.device)
-        with torch.no_grad():
+    def _forward_mean(self, inputs):
+        with self.torch.no_grad():
             return self.model(**inputs).last_hidden_state.mean(dim=1)
+
+    def _pool(self, texts: List[str]):
+        """:167-169, on the device (the embeddings stay there for `HxIndex.add_device`)"""
+        return self._forward_mean(self.tokenizer(texts, padding=True, return_tensors="pt").to(self.device))
 
     async def embed_text(self, texts: List[str]) -> List[List[float]]:
         return self._pool(texts).float().cpu().numpy().tolist()
 
     def rerank_documents(self, query: str, documents: List[str], max_tokens: int) -> List[int]:
-        if not documents:
-            return []
-        docs = [d[: max_tokens * 4] for d in documents]       # character truncation, :177-182
-        q = self._pool([query])
-        d = self._pool(docs)
-        scores = self.torch.matmul(q, d.T).squeeze(0).float().cpu().numpy()
         import numpy as np
+        query_tokens = self.tokenizer(query, return_tensors="pt").to(self.device)
+        doc_tokens = self.tokenizer(documents, return_tensors="pt", padding=True).to(self.device)
+        if len(doc_tokens) > 8000:          # number of keys of the BatchEncoding (see the class docstring)
+            documents = [doc[:max_tokens - 5] + "....." for doc in documents]
+            doc_tokens = self.tokenizer(documents, return_tensors="pt", padding=True).to(self.device)
+        query_embedding = self._forward_mean(query_tokens)
+        doc_embeddings = self._forward_mean(doc_tokens)
+        scores = self.torch.matmul(query_embedding, doc_embeddings.T).squeeze().float().cpu().numpy()
         return np.argsort(scores)[::-1].tolist()
 
 

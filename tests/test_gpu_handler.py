@@ -213,6 +213,13 @@ def test_local_hf_encoder_on_the_gpu_feeds_the_index(tmp_path):
     got = np.asarray(run(gpu.embed_text(texts[:4])), np.float32)
     np.testing.assert_allclose(got, np.asarray(run(cpu.embed_text(texts[:4])), np.float32), rtol=0, atol=1e-5)
     assert gpu.rerank_documents(texts[0], texts[:10], 100) == cpu.rerank_documents(texts[0], texts[:10], 100)
+    # documents far longer than max_tokens characters: the reference's truncation branch does not run for a real
+    # tokenizer (huggingface.py:177-182: len() of a BatchEncoding), so the whole documents are scored -- on both devices
+    long_docs = [" ".join(f"w{int(t)}" for t in rng.integers(0, 200, 40)) for _ in range(6)]
+    order = gpu.rerank_documents(texts[0], long_docs, 12)
+    assert order == cpu.rerank_documents(texts[0], long_docs, 12)
+    q = cpu._pool([texts[0]])[0].numpy()
+    assert order == np.argsort(cpu._pool(long_docs).numpy() @ q)[::-1].tolist()
     # the vectors go into the index where they lie (hx_add_dense_dev) and come back as their own nearest neighbours
     ix = eng.HxIndex(128, (64,))
     ix.add_device(on_dev.contiguous())

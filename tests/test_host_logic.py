@@ -220,7 +220,7 @@ def test_local_hf_encoder_unmasked_mean_and_rerank(tmp_path):
     enc = LocalHFEncoder(str(tmp_path), device="cpu")
     texts = ["hybrid dense sparse retrieval", "kernel", "the query of a document engine wave front"]
     got = np.asarray(asyncio.run(enc.embed_text(texts)), np.float32)
-    inputs = enc.tokenizer(texts, return_tensors="pt", padding=True, truncation=True)
+    inputs = enc.tokenizer(texts, return_tensors="pt", padding=True)
     with torch.no_grad():
         ref = enc.model(**inputs).last_hidden_state.mean(dim=1).numpy()      # padding positions included
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
@@ -228,7 +228,26 @@ def test_local_hf_encoder_unmasked_mean_and_rerank(tmp_path):
     order = enc.rerank_documents("dense retrieval", texts, max_tokens=100)
     q = np.asarray(asyncio.run(enc.embed_text(["dense retrieval"])), np.float32)[0]
     assert order == np.argsort(got @ q)[::-1].tolist()
-    assert enc.rerank_documents("x", [], 10) == []
+    # the reference's truncation branch tests len() of the tokenizer's BatchEncoding = its number of keys, so a
+    # document far longer than max_tokens characters is NOT cut (huggingface.py:177-182 as written): the order is
+    # that of the whole documents
+    long_docs = ["dense " * 20 + "kernel", "sparse " * 20 + "wave", "query document"]
+    assert len(enc.tokenizer(long_docs, return_tensors="pt", padding=True)) < 8000
+    whole = np.asarray(asyncio.run(enc.embed_text(long_docs)), np.float32)
+    assert enc.rerank_documents("dense retrieval", long_docs, max_tokens=12) == np.argsort(whole @ q)[::-1].tolist()
+    cut = np.asarray(asyncio.run(enc.embed_text([d[:12 - 5] + "....." for d in long_docs])), np.float32)
+    assert not np.allclose(cut @ q, whole @ q)          # (the cut documents would have scored differently)
+    # no truncation anywhere (:167): a text beyond the model's 64 positions fails inside the model -- the rerank
+    # hook then keeps the order (qdrant_handler.py:410-412), encode_dense returns [] (embedding_handler.py:96-98)
+    too_long = "kernel " * 80
+    with pytest.raises(Exception):
+        enc.rerank_documents("dense", [too_long], 10)
+    with pytest.raises(Exception):
+        enc.rerank_documents("x", [], 10)                 # as upstream: the tokenizer refuses an empty batch
+    from rag_application_amd.handler import QdrantHandler
+    res = ["r0"]
+    assert asyncio.run(QdrantHandler(reranker=enc).rerank_with_colbert("dense", [too_long], res, 10)) is res
+    assert asyncio.run(EmbeddingHandler(model_name=str(tmp_path)).encode_dense(too_long)) == []
     # through the EmbeddingHandler drop-in: model_name = local path
     h = EmbeddingHandler(model_name=str(tmp_path))
     out = asyncio.run(h.encode_dense(texts[0]))
