@@ -153,6 +153,20 @@ int hx_search_sparse(hx_index* h, const int64_t* q_indptr_dev, const int32_t* q_
                      const float* q_val_dev, int32_t B, int32_t limit,
                      uint64_t* keys_dev, int32_t* counts_dev, void* stream);
 
+/* The three stages above WITHOUT their host round trip (the reference has no multi-device path; these serve the
+ * row-sharded form of its query tree, qdrant_handler.py:305-372, where every rank enqueues a level, the ranks exchange
+ * the level's lists, and nobody should wait for a flag in between): everything is enqueued on `stream` and the call
+ * returns; the number of queries whose lists are NOT final (a stage flagged them for a retry or the exact path) is
+ * ADDED to *flag_dev (device).  The caller zeroes the word before the first stage of a batch, reads it when it suits
+ * it -- once, behind the whole tree -- and runs the batch again through the synchronous entries when it is not zero. */
+int hx_search_dense_async(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, int32_t limit,
+                          uint64_t* keys_dev, int32_t* counts_dev, int32_t* flag_dev, void* stream);
+int hx_search_i8_async(hx_index* h, const float* q_dev, int32_t B, int32_t limit,
+                       uint64_t* keys_dev, int32_t* counts_dev, int32_t* flag_dev, void* stream);
+int hx_search_sparse_async(hx_index* h, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
+                           const float* q_val_dev, int32_t B, int32_t limit,
+                           uint64_t* keys_dev, int32_t* counts_dev, int32_t* flag_dev, void* stream);
+
 /* ---- candidate stages ------------------------------------------------------ */
 
 /* outer level of a nested Prefetch / the root query (qdrant_handler.py:307-330,
@@ -250,6 +264,7 @@ typedef struct hx_stats {
   int64_t cand8_queries;
   int64_t cand8_uncertified_queries;
   double  cand8_row_error_max;      /* largest ||x - scale * x8||_2 of any stored row: what the certificate is built from */
+  int64_t tree_batches_redone;      /* HX_MODE_TREE batches whose deferred flag word was set: run again stage by stage */
 } hx_stats;
 int hx_get_stats(hx_index* h, hx_stats* out);
 /* HIP-event profile of the hot kernels, measured on the stream they run on.

@@ -38,7 +38,8 @@ class HxStats(C.Structure):
         "n_rows", "nnz", "n_segments", "n_groups", "hash_capacity", "bytes_dense_f32",
         "bytes_dense_f16", "bytes_i8", "bytes_prefix", "bytes_sparse",
         "dense_fallback_queries", "i8_fallback_queries", "retry_queries", "sparse_fallback_queries",
-        "bytes_i8_cand", "cand8_queries", "cand8_uncertified_queries")] + [("cand8_row_error_max", C.c_double)]
+        "bytes_i8_cand", "cand8_queries", "cand8_uncertified_queries")] + [("cand8_row_error_max", C.c_double),
+                                                                              ("tree_batches_redone", C.c_int64)]
 
 
 class HxProf(C.Structure):
@@ -67,6 +68,9 @@ _SIGS = {
     "hx_search_dense": [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P],
     "hx_search_i8": [_P, _P, C.c_int32, C.c_int32, _P, _P, _P],
     "hx_search_sparse": [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P],
+    "hx_search_dense_async": [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P],
+    "hx_search_i8_async": [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P],
+    "hx_search_sparse_async": [_P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P],
     "hx_rescore": [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, _P],
     "hx_rrf": [C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32, C.c_float, C.c_int32,
                C.c_int32, _P, _P, _P],

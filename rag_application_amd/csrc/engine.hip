@@ -92,7 +92,7 @@ enum WsSlot {
   WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC,
   WS_SP_TI0, WS_SP_TI1, WS_SP_QS, WS_SP_MARGIN, WS_SP_FLAG, WS_SP_WORK, WS_SP_FAIL, WS_SP_LIST, WS_SP_LCNT,
   WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF, WS_SP_QPARTS, WS_SP_SUM,
-  WS_ID_IN, WS_LONG_ROWS, WS_Q8S, WS_SQ, WS_EPSQ
+  WS_ID_IN, WS_LONG_ROWS, WS_Q8S, WS_SQ, WS_EPSQ, WS_TREE_FLAG
 };
 
 template <typename T>
@@ -130,6 +130,7 @@ struct hx_index {
   int cand8 = 1;                      // 0: fp16 candidates only, no int8 copy is kept (HX_DENSE_CAND=f16)
   bool cand8_off = false;             // hx_set_dense_candidates(h, 0): the copy is kept but the fp16 scan nominates
   int64_t cand8_queries = 0, cand8_failed = 0;   // queries the int8 candidate pass took / could not certify
+  int64_t tree_redone = 0;            // tree batches run again the synchronous way (a deferred flag was set)
   // doc-major sparse staging (device)
   int64_t* sp_indptr = nullptr;  // [sp_rows_cap + 1]
   int32_t* sp_idx = nullptr;
@@ -782,9 +783,12 @@ static void retry_subset(hx_index* h, const float* q_dev, const std::vector<int>
 // retry or the exact path rewrote rows of out_keys after `between` ran (then the caller redoes it).
 // `defer`: enqueue only -- no flag read, no retry; the stage's failure count stays in WS_NFAIL (level 0) for
 // the caller (hx_h1_local_async), who redoes the batch through the synchronous path if it is not zero.
+// `flag_acc` (with `defer`): the device word the stage ADDS its failure count to instead of WS_NFAIL -- several
+// deferred stages of one query tree share it and the caller reads it once (hx_*_async, the tree of hybrid_query_dev).
 static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int L, uint64_t* out_keys,
                          int* out_cnt, hipStream_t st, int level = 0,
-                         const std::function<void()>& between = std::function<void()>(), bool defer = false) {
+                         const std::function<void()>& between = std::function<void()>(), bool defer = false,
+                         int* flag_acc = nullptr) {
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   if (h->n == 0) {
@@ -844,7 +848,8 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     r.out = cand2;
     launch_rescore_list(r, st);
     launch_compact(cand2, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
-    HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
+    if (defer && flag_acc) nfail = flag_acc;
+    else HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
     launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st, eps_q);
     if (between) between();
     if (defer) return false;
@@ -862,7 +867,7 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     std::iota(sel.begin(), sel.end(), 0);
     if (between) between();
     if (defer) {                         // no fp16 copy to scan: every query needs the exact path
-      launch_fill_i32(nfail, 1, B, st);
+      launch_fill_i32(flag_acc ? flag_acc : nfail, 1, B, st);
       return false;
     }
   }
@@ -876,7 +881,7 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
 }
 
 static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* out_keys, int* out_cnt,
-                      hipStream_t st, int level = 0) {
+                      hipStream_t st, int level = 0, int* flag_acc = nullptr) {   // flag_acc: deferred, as search_dense
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
@@ -897,9 +902,11 @@ static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* o
                tau, rq, st);
   // the scan's scores are already exact: the list is final unless a buffer overflowed
   launch_compact(cand, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
-  HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
+  if (flag_acc) nfail = flag_acc;
+  else HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
   launch_certify(cand, g.C, cnt, std::numeric_limits<int>::max(), out_keys, L, out_cnt, L, ovf, 0.f, B,
                  fail, nfail, st);
+  if (flag_acc) return;
   std::vector<int> sel = read_failures(h, fail, nfail, B, st);
   if (sel.empty()) return;
   if (level == 0) {
@@ -1231,7 +1238,7 @@ static void rrf(hx_index* h, const uint64_t* a, int as, const int* ac, const uin
 
 static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix,
                              const float* qv, int B, const hx_params* p, uint64_t* out_keys, int* out_cnt,
-                             hipStream_t st) {
+                             hipStream_t st, bool tree_sync = false) {
   // A batch beyond 4096 queries goes through in equal slices: the scan's threshold table and the sparse launch
   // plan end there (measured on 10M x 768: B = 5000 in one piece 100 ms, in two slices 75 ms; slicing at 2048
   // instead changes nothing at 4096 and costs 3 % at 5000), and a slice reads the query CSR through the same offsets.
@@ -1241,7 +1248,7 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     for (int b0 = 0; b0 < B; b0 += per) {
       const int nb = std::min(per, B - b0);
       hybrid_query_dev(h, qd + (int64_t)b0 * h->dim, qip + b0, qix, qv, nb, p, out_keys + (int64_t)b0 * p->final_limit,
-                       out_cnt + b0, st);
+                       out_cnt + b0, st, tree_sync);
     }
     return;
   }
@@ -1268,16 +1275,31 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     if (patched || sp_patched) fuse();
     return;
   }
+  // The tree's three whole-collection stages (prefix scan, int8 scan, sparse) each end with a look at their failure
+  // flags.  Speculatively they do not: every stage is enqueued with its flags deferred into ONE device word, the
+  // host reads that word once behind the whole tree, and a batch with a flagged query (a retry or the exact path was
+  // needed: rare) is run again the synchronous way.  Round 2 read the flags three times per batch, with the device
+  // idle each time (146 us of a 12.2 ms step).
+  static const bool no_spec = getenv("HX_DEBUG_TREE_SYNC") != nullptr;
+  int* tflag = nullptr;
+  if (!no_spec && !tree_sync) {
+    tflag = (int*)w.get(WS_TREE_FLAG, 4);
+    HX_HIP(hipMemsetAsync(tflag, 0, 4, st));
+  }
+  auto dense_stage = [&](int prefix, int L, uint64_t* ok, int* oc) {
+    if (tflag) search_dense(h, qd, B, prefix, L, ok, oc, st, 0, std::function<void()>(), true, tflag);
+    else search_dense(h, qd, B, prefix, L, ok, oc, st);
+  };
   // --- matryoshka cascade (qdrant_handler.py:305-330)
   const int lim[3] = {p->matryoshka_64_limit, p->matryoshka_128_limit, p->matryoshka_256_limit};
   uint64_t* A = keys(WS_T_A, p->dense_limit);
   int* Ac = cnts(WS_T_ACNT);
   if (h->n_pre == 0) {
-    search_dense(h, qd, B, 0, p->dense_limit, A, Ac, st);
+    dense_stage(0, p->dense_limit, A, Ac);
   } else {
     uint64_t* c0 = keys(WS_T_C, lim[0]);
     int* c0c = cnts(WS_T_CCNT);
-    search_dense(h, qd, B, h->psize[0], lim[0], c0, c0c, st);
+    dense_stage(h->psize[0], lim[0], c0, c0c);
     uint64_t* cur = c0;
     int* curc = c0c;
     int curL = lim[0];
@@ -1295,14 +1317,20 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
   // --- quantized -> dense refinement (:333-344)
   uint64_t* Qc = keys(WS_T_C, p->quantized_limit);
   int* Qcc = cnts(WS_T_CCNT);
-  search_i8(h, qd, B, p->quantized_limit, Qc, Qcc, st);
+  search_i8(h, qd, B, p->quantized_limit, Qc, Qcc, st, 0, tflag);
   uint64_t* Dq = keys(WS_T_D, p->dense_limit);
   int* Dqc = cnts(WS_T_DCNT);
   rescore(h, qd, B, 0, Qc, p->quantized_limit, Qcc, p->dense_limit, Dq, Dqc, st);
   // --- sparse (:347-354)
   uint64_t* S = keys(WS_T_B, p->sparse_limit);
   int* Sc = cnts(WS_T_BCNT);
-  search_sparse(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+  if (tflag) {
+    sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+    h->sp_sum_pending = false;          // its summary is read with the tree's flag word below
+    h->sp_sum_fetched = false;
+  } else {
+    search_sparse(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+  }
   // --- RRF (:357-360)
   uint64_t* R = keys(WS_T_E, p->rrf_limit);
   int* Rc = cnts(WS_T_ECNT);
@@ -1312,6 +1340,18 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
   uint64_t* U = keys(WS_T_F, us);
   launch_concat(A, p->dense_limit, Ac, R, p->rrf_limit, Rc, B, U, st);
   rescore(h, qd, B, 0, U, us, nullptr, p->final_limit, out_keys, out_cnt, st);
+  if (tflag) {                           // the one look at the flags
+    int* pin = host_pin(h);
+    pin[1] = pin[2] = 0;
+    HX_HIP(hipMemcpyAsync(pin, tflag, 4, hipMemcpyDeviceToHost, st));
+    if (h->sp_base.n_segments || h->sp_tail.n_segments)
+      HX_HIP(hipMemcpyAsync(pin + 1, w.get(WS_SP_SUM, 8), 8, hipMemcpyDeviceToHost, st));
+    HX_HIP(hipStreamSynchronize(st));
+    if (pin[0] | pin[1] | pin[2]) {      // some list is not final: the batch again, every stage resolving its own flags
+      h->tree_redone += 1;
+      hybrid_query_dev(h, qd, qip, qix, qv, B, p, out_keys, out_cnt, st, true);
+    }
+  }
 }
 
 static void check_params(const hx_params* p) {
@@ -1767,6 +1807,45 @@ int hx_search_sparse(hx_index* h, const int64_t* q_indptr_dev, const int32_t* q_
   HX_CATCH
 }
 
+// ---- the whole-collection stages without their host round trip (hx.h: hx_*_async) -------------------------------
+int hx_search_dense_async(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, int32_t limit, uint64_t* keys_dev,
+                          int32_t* counts_dev, int32_t* flag_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && q_dev && keys_dev && counts_dev && flag_dev, "NULL argument");
+  h->set_device();
+  search_dense(h, q_dev, B, prefix, limit, keys_dev, counts_dev, (hipStream_t)stream, 0, std::function<void()>(), true,
+               flag_dev);
+  remap_out(h, keys_dev, (int64_t)B * limit, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_search_i8_async(hx_index* h, const float* q_dev, int32_t B, int32_t limit, uint64_t* keys_dev, int32_t* counts_dev,
+                       int32_t* flag_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && q_dev && keys_dev && counts_dev && flag_dev, "NULL argument");
+  h->set_device();
+  search_i8(h, q_dev, B, limit, keys_dev, counts_dev, (hipStream_t)stream, 0, flag_dev);
+  remap_out(h, keys_dev, (int64_t)B * limit, (hipStream_t)stream);
+  HX_CATCH
+}
+
+int hx_search_sparse_async(hx_index* h, const int64_t* q_indptr_dev, const int32_t* q_idx_dev, const float* q_val_dev,
+                           int32_t B, int32_t limit, uint64_t* keys_dev, int32_t* counts_dev, int32_t* flag_dev,
+                           void* stream) {
+  HX_TRY
+  HX_CHECK(h && q_indptr_dev && keys_dev && counts_dev && flag_dev, "NULL argument");
+  h->set_device();
+  hipStream_t st = (hipStream_t)stream;
+  int* spsum = (int*)h->ws.get(WS_SP_SUM, 8);
+  HX_HIP(hipMemsetAsync(spsum, 0, 8, st));            // (an index without postings enqueues nothing)
+  sparse_enqueue(h, q_indptr_dev, q_idx_dev, q_val_dev, B, limit, keys_dev, counts_dev, st);
+  h->sp_sum_pending = false;                          // nobody will call sparse_resolve for this batch
+  h->sp_sum_fetched = false;
+  launch_flag_add(flag_dev, spsum, st);
+  remap_out(h, keys_dev, (int64_t)B * limit, st);
+  HX_CATCH
+}
+
 int hx_rescore(hx_index* h, const float* q_dev, int32_t B, int32_t prefix, const uint64_t* cand_keys_dev,
                int32_t cand_stride, const int32_t* cand_counts_dev, int32_t limit, uint64_t* keys_dev,
                int32_t* counts_dev, void* stream) {
@@ -1998,6 +2077,7 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
     HX_HIP(hipMemcpy(&emax, h->s8_err, 4, hipMemcpyDeviceToHost));
   }
   out->cand8_row_error_max = (double)emax;
+  out->tree_batches_redone = h->tree_redone;
   HX_CATCH
 }
 

@@ -136,6 +136,7 @@ void launch_scan_init(float* tau, int* cnt, int* ovf, int* kept, int B, int cnt0
 void launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st);
 void launch_flag_row(const int* nfail, const int* spsum, uint64_t* row, int len, hipStream_t st);
+void launch_flag_add(int* acc, const int* add2, hipStream_t st);   // *acc += add2[0] + add2[1]
 // internal id (id_base + local row) <-> global insertion-order id through the index's block table (select.hip)
 void launch_remap_ids(const uint64_t* in, uint64_t* out, int64_t n, const uint32_t* row0, const uint32_t* gid0, int nb,
                       uint32_t id_base, uint32_t n_rows, int to_global, hipStream_t st);

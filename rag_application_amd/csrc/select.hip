@@ -557,6 +557,18 @@ void launch_remap_ids(const uint64_t* in, uint64_t* out, int64_t n, const uint32
   HX_HIP(hipGetLastError());
 }
 
+// *acc += add[0] + add[1] (a deferred stage folds its summary into the caller's flag word)
+__global__ void k_flag_add(int* acc, const int* add) {
+  if (threadIdx.x == 0) {
+    const int v = add[0] + add[1];
+    if (v) atomicAdd(acc, v);
+  }
+}
+void launch_flag_add(int* acc, const int* add, hipStream_t st) {
+  hipLaunchKernelGGL(k_flag_add, dim3(1), dim3(64), 0, st, acc, add);
+  HX_HIP(hipGetLastError());
+}
+
 void launch_fill_i32(int* p, int64_t n, int v, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_fill<int>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);

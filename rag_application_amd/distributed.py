@@ -36,15 +36,16 @@ class ShardedIndex:
         # happens, on every rank, in the same order), and the caller exchanges `take_error()` at the end of the
         # call -- a failed rank makes the whole call fail on every rank (sharded.ShardedCollection.search).
         self.err: Optional[BaseException] = None
+        self.redone = 0              # tree batches run again because a rank's deferred flag word was set
 
     def take_error(self) -> Optional[BaseException]:
         e, self.err = self.err, None
         return e
 
-    def _local(self, name: str, B: int, width: int, like: torch.Tensor, *args, counts: bool = True):
+    def _local(self, name: str, B: int, width: int, like: torch.Tensor, *args, counts: bool = True, **kw):
         if self.err is None:
             try:
-                return getattr(self.local, name)(*args)
+                return getattr(self.local, name)(*args, **kw)
             except Exception as e:            # kept for the status exchange; the collectives go on
                 self.err = e
         k = torch.zeros((B, width), dtype=torch.int64, device=like.device)
@@ -78,16 +79,21 @@ class ShardedIndex:
         return self.ops.merge(self.gather(keys), None, limit, dedupe)
 
     # -- stages: global lists, replicated on every rank ----------------------------------
-    def search_dense(self, q, limit, prefix=0):
-        k, c = self._local("search_dense", q.shape[0], limit, q, q, limit, prefix)
+    # `flag` (engine.HxIndex: a zeroed int32 device word): the local stage is enqueued without its host round trip and
+    # adds its failure count to the word (hx_*_async); hybrid_tree reads it once behind the whole tree
+    def search_dense(self, q, limit, prefix=0, flag=None):
+        kw = {} if flag is None else {"flag": flag}
+        k, c = self._local("search_dense", q.shape[0], limit, q, q, limit, prefix, **kw)
         return (k, c) if self.world == 1 else self._global(k, limit)
 
-    def search_i8(self, q, limit):
-        k, c = self._local("search_i8", q.shape[0], limit, q, q, limit)
+    def search_i8(self, q, limit, flag=None):
+        kw = {} if flag is None else {"flag": flag}
+        k, c = self._local("search_i8", q.shape[0], limit, q, q, limit, **kw)
         return (k, c) if self.world == 1 else self._global(k, limit)
 
-    def search_sparse(self, q_indptr, q_idx, q_val, limit):
-        k, c = self._local("search_sparse", q_indptr.shape[0] - 1, limit, q_indptr, q_indptr, q_idx, q_val, limit)
+    def search_sparse(self, q_indptr, q_idx, q_val, limit, flag=None):
+        kw = {} if flag is None else {"flag": flag}
+        k, c = self._local("search_sparse", q_indptr.shape[0] - 1, limit, q_indptr, q_indptr, q_idx, q_val, limit, **kw)
         return (k, c) if self.world == 1 else self._global(k, limit)
 
     def rescore(self, q, cand_keys, cand_counts, limit, prefix=0):
@@ -115,19 +121,43 @@ class ShardedIndex:
         return self.ops.rrf(dk, dc, sk, sc, limit, rrf_k, rank_base)
 
     def hybrid_tree(self, q, q_indptr, q_idx, q_val, p: dict, msizes=(64, 128, 256), rrf_k=2.0, rank_base=0,
-                    rrf_limit=10):
-        """The reference tree with one exchange per cascade level."""
+                    rrf_limit=10, deferred: Optional[bool] = None):
+        """The reference tree (qdrant_handler.py:305-372) with one exchange per cascade level.
+        `deferred` (default: whenever the shard offers it): every level is enqueue -> all-gather -> enqueue, the three
+        whole-collection stages keep their failure flags on the device (one word per rank), and the word is looked at
+        ONCE behind the whole tree -- summed over the ranks, so that all of them take the same decision.  A batch with
+        a flagged query anywhere (rare) is run again with every stage resolving its own flags (`self.redone` counts
+        them).  Without it every one of the three stages parks the host -- and with it the device -- on its flags."""
+        if deferred is None:
+            deferred = bool(getattr(self.local, "deferred_stages", False))
+        if not deferred:
+            return self._tree(q, q_indptr, q_idx, q_val, p, msizes, rrf_k, rank_base, rrf_limit, None)
+        flag = torch.zeros(1, dtype=torch.int32, device=q.device)
+        out = self._tree(q, q_indptr, q_idx, q_val, p, msizes, rrf_k, rank_base, rrf_limit, flag)
+        if self.world > 1:
+            if dist.get_backend(self.group) == "gloo":
+                host = flag.cpu()
+                dist.all_reduce(host, group=self.group)
+                flag = host
+            else:
+                dist.all_reduce(flag, group=self.group)
+        if int(flag.item()) != 0:           # the one host look at the flags of the batch
+            self.redone = getattr(self, "redone", 0) + 1
+            out = self._tree(q, q_indptr, q_idx, q_val, p, msizes, rrf_k, rank_base, rrf_limit, None)
+        return out
+
+    def _tree(self, q, q_indptr, q_idx, q_val, p, msizes, rrf_k, rank_base, rrf_limit, flag):
         lim = [p[f"matryoshka_{m}_limit"] for m in msizes]
         if msizes:
-            ck, cc = self.search_dense(q, lim[0], msizes[0])
+            ck, cc = self.search_dense(q, lim[0], msizes[0], flag=flag)
             for m, l in zip(msizes[1:], lim[1:]):
                 ck, cc = self.rescore(q, ck, cc, l, m)
             ak, ac = self.rescore(q, ck, cc, p["dense_limit"], 0)
         else:
-            ak, ac = self.search_dense(q, p["dense_limit"], 0)
-        qk, qc = self.search_i8(q, p["quantized_limit"])
+            ak, ac = self.search_dense(q, p["dense_limit"], 0, flag=flag)
+        qk, qc = self.search_i8(q, p["quantized_limit"], flag=flag)
         dk, dc = self.rescore(q, qk, qc, p["dense_limit"], 0)
-        sk, sc = self.search_sparse(q_indptr, q_idx, q_val, p["sparse_limit"])
+        sk, sc = self.search_sparse(q_indptr, q_idx, q_val, p["sparse_limit"], flag=flag)
         if dc is None:
             dc = torch.full((q.shape[0],), dk.shape[1], dtype=torch.int32, device=dk.device)
         if sc is None:

@@ -195,27 +195,46 @@ class HxIndex:
         return (torch.empty((B, L), dtype=torch.int64, device=self._tdev),
                 torch.empty((B,), dtype=torch.int32, device=self._tdev))
 
-    def search_dense(self, q: torch.Tensor, limit: int, prefix: int = 0):
+    # `flag` (a zeroed int32 device tensor of one element): the stage is only ENQUEUED -- no host round trip -- and
+    # adds to flag[0] the number of queries whose lists are not final (hx_*_async); the caller reads the word once
+    # behind all the stages of its query and redoes the batch without `flag` when it is not zero.
+    deferred_stages = True
+
+    def search_dense(self, q: torch.Tensor, limit: int, prefix: int = 0, flag: Optional[torch.Tensor] = None):
         q = _need_cuda(q, torch.float32, "q")
         keys, cnt = self._out(q.shape[0], limit)
-        check(_lib.lib().hx_search_dense(self._h, _ptr(q), q.shape[0], prefix, limit, _ptr(keys), _ptr(cnt),
-                                         _stream()))
+        if flag is not None:
+            check(_lib.lib().hx_search_dense_async(self._h, _ptr(q), q.shape[0], prefix, limit, _ptr(keys), _ptr(cnt),
+                                                   _ptr(_need_cuda(flag, torch.int32, "flag")), _stream()))
+        else:
+            check(_lib.lib().hx_search_dense(self._h, _ptr(q), q.shape[0], prefix, limit, _ptr(keys), _ptr(cnt),
+                                             _stream()))
         return keys, cnt
 
-    def search_i8(self, q: torch.Tensor, limit: int):
+    def search_i8(self, q: torch.Tensor, limit: int, flag: Optional[torch.Tensor] = None):
         q = _need_cuda(q, torch.float32, "q")
         keys, cnt = self._out(q.shape[0], limit)
-        check(_lib.lib().hx_search_i8(self._h, _ptr(q), q.shape[0], limit, _ptr(keys), _ptr(cnt), _stream()))
+        if flag is not None:
+            check(_lib.lib().hx_search_i8_async(self._h, _ptr(q), q.shape[0], limit, _ptr(keys), _ptr(cnt),
+                                                _ptr(_need_cuda(flag, torch.int32, "flag")), _stream()))
+        else:
+            check(_lib.lib().hx_search_i8(self._h, _ptr(q), q.shape[0], limit, _ptr(keys), _ptr(cnt), _stream()))
         return keys, cnt
 
-    def search_sparse(self, q_indptr: torch.Tensor, q_idx: torch.Tensor, q_val: torch.Tensor, limit: int):
+    def search_sparse(self, q_indptr: torch.Tensor, q_idx: torch.Tensor, q_val: torch.Tensor, limit: int,
+                      flag: Optional[torch.Tensor] = None):
         q_indptr = _need_cuda(q_indptr, torch.int64, "q_indptr")
         q_idx = _need_cuda(q_idx, torch.int32, "q_idx")
         q_val = _need_cuda(q_val, torch.float32, "q_val")
         B = q_indptr.shape[0] - 1
         keys, cnt = self._out(B, limit)
-        check(_lib.lib().hx_search_sparse(self._h, _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, limit,
-                                          _ptr(keys), _ptr(cnt), _stream()))
+        if flag is not None:
+            check(_lib.lib().hx_search_sparse_async(self._h, _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, limit,
+                                                    _ptr(keys), _ptr(cnt), _ptr(_need_cuda(flag, torch.int32, "flag")),
+                                                    _stream()))
+        else:
+            check(_lib.lib().hx_search_sparse(self._h, _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, limit,
+                                              _ptr(keys), _ptr(cnt), _stream()))
         return keys, cnt
 
     def h1_local(self, q: torch.Tensor, q_indptr: torch.Tensor, q_idx: torch.Tensor, q_val: torch.Tensor,

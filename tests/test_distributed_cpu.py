@@ -71,6 +71,30 @@ class FakeShard:
         return keys_of(out, limit)
 
 
+class FakeShardDeferred(FakeShard):
+    """... whose whole-collection stages take `flag` (engine.HxIndex with hx_*_async): the stage adds to flag[0] the
+    number of queries whose lists are not final -- `bad_calls`: the search_i8 calls (by number) on which this
+    stand-in pretends so, and hands out garbage"""
+    deferred_stages = True
+    bad_calls = ()
+    n_i8 = 0
+
+    def search_dense(self, q, limit, prefix=0, flag=None):
+        return super().search_dense(q, limit, prefix)
+
+    def search_sparse(self, qip, qix, qv, limit, flag=None):
+        return super().search_sparse(qip, qix, qv, limit)
+
+    def search_i8(self, q, limit, flag=None):
+        k, c = super().search_i8(q, limit)
+        if flag is not None:
+            if self.n_i8 in self.bad_calls:
+                flag[0] += 2
+                k = torch.zeros_like(k)
+            self.n_i8 += 1
+        return k, c
+
+
 class CpuOps:
     @staticmethod
     def merge(keys, counts, limit, dedupe):
@@ -153,6 +177,15 @@ def worker(rank, world, port, n, dim, B, ret):
     tk, tc = sh.hybrid_tree(Q, *tq, P)
     hk, hc = sh.hybrid_h1(Q, *tq, 40, 30, 10)
     dk, dc = sh.search_dense(Q, 15)
+    # the tree with deferred flags (hx_*_async): rank 1 flags its SECOND batch, every rank redoes that batch and only it
+    fd = FakeShardDeferred(ora, r0)
+    if rank == 1:
+        fd.bad_calls = (1,)
+    shd = ShardedIndex(fd, ops=CpuOps)
+    for _ in range(3):
+        t2k, t2c = shd.hybrid_tree(Q, *tq, P)
+        assert torch.equal(t2k, tk) and torch.equal(t2c, tc)
+    assert shd.redone == 1
     # the same H1 query through the two calls that bracket the single exchange of the step
     h2k, h2c = ShardedIndex(FakeShardH1(ora, r0), ops=CpuOpsH1).hybrid_h1(Q, *tq, 40, 30, 10)
     assert torch.equal(h2k, hk) and torch.equal(h2c, hc)

@@ -1375,3 +1375,78 @@ def test_int8_candidate_copy_survives_save_load_and_truncate(eng, torch_mod, tmp
     assert torch_mod.equal(k2, k3) and torch_mod.equal(c2, c3)
     for i in (ix, ld, ref):
         i.close()
+
+
+# ---- the query tree without per-stage host round trips (deferred flags) --------------------------------------------------
+def test_tree_stages_deferred_flags(eng, torch_mod, synth_tables, monkeypatch):
+    """(a) hx_search_*_async return the synchronous stages' keys and leave the flag word at 0 on a benign batch;
+    (b) with per-wave scan logs of 4 entries (HX_DEBUG_SCAN8_LOGCAP) the int8 and prefix scans flag queries: the async
+    stages report them in the flag word, hx_hybrid_query_dev's tree runs the batch again stage by stage
+    (stats.tree_batches_redone) and still returns the oracle's lists."""
+    n, dim, B = 40000, 128, 150
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    ora = O.OracleIndex(dim, (64,))
+    ora.add(X, ip, si, sv)
+    ora.finalize()
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
+    P = dict(matryoshka_64_limit=80, matryoshka_128_limit=1, matryoshka_256_limit=1, dense_limit=30, quantized_limit=35,
+             sparse_limit=25, final_limit=12, hnsw_ef=1)
+    hp = eng.make_params(P, mode=eng.HX_MODE_TREE)
+
+    def check_tree(ix, what):
+        s, i, c = unpack_np(eng, *ix.hybrid_query(Qd, *tq, hp))
+        for b in range(B):
+            es, ei = O.hybrid_tree(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], dict(P), )
+            assert_list_equal(s[b], i[b], c[b], es, ei, f"{what} b={b}")
+
+    ix = eng.HxIndex(dim, (64,))
+    ix.add(X, ip, si.astype(np.int32), sv)
+    flag = torch_mod.zeros(1, dtype=torch_mod.int32, device="cuda")
+    for sync, asyn in ((ix.search_dense(Qd, 80, 64), ix.search_dense(Qd, 80, 64, flag=flag)),
+                       (ix.search_dense(Qd, 30), ix.search_dense(Qd, 30, flag=flag)),
+                       (ix.search_i8(Qd, 35), ix.search_i8(Qd, 35, flag=flag)),
+                       (ix.search_sparse(*tq, 25), ix.search_sparse(*tq, 25, flag=flag))):
+        assert torch_mod.equal(sync[0], asyn[0]) and torch_mod.equal(sync[1], asyn[1])
+    assert int(flag.item()) == 0
+    check_tree(ix, "deferred")
+    assert ix.stats()["tree_batches_redone"] == 0
+    ix.close()
+    monkeypatch.setenv("HX_DEBUG_SCAN8_LOGCAP", "4")
+    bad = eng.HxIndex(dim, (64,))
+    bad.add(X, ip, si.astype(np.int32), sv)
+    flag.zero_()
+    bad.search_i8(Qd, 35, flag=flag)
+    assert int(flag.item()) > 0
+    check_tree(bad, "flagged")
+    assert bad.stats()["tree_batches_redone"] == 1
+    # ... and the row-sharded tree: two shards on one GPU, the exchange emulated; the flagged batch is redone once
+    from rag_application_amd.distributed import ShardedIndex
+    h = n // 2
+    shards = []
+    for r0, r1 in ((0, h), (h, n)):
+        sx = eng.HxIndex(dim, (64,), id_base=r0)
+        sx.add(X[r0:r1], ip[r0:r1 + 1] - ip[r0], si[ip[r0]:ip[r1]].astype(np.int32), sv[ip[r0]:ip[r1]])
+        shards.append(sx)
+
+    class Both:                      # rank 0's view: its own shard, with the other shard's lists "gathered" on the spot
+        deferred_stages = True
+
+        def __getattr__(self, name):
+            def call(*a, **kw):
+                k0, c0 = getattr(shards[0], name)(*a, **kw)
+                k1, c1 = getattr(shards[1], name)(*a, **kw)
+                return eng.merge(torch_mod.cat([k0, k1], dim=1), None, k0.shape[1], False)
+            return call
+
+    sh = ShardedIndex(Both())
+    s, i, c = unpack_np(eng, *sh.hybrid_tree(Qd, *tq, P, (64,)))
+    for b in range(B):
+        es, ei = O.hybrid_tree(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], dict(P))
+        assert_list_equal(s[b], i[b], c[b], es, ei, f"sharded deferred b={b}")
+    assert sh.redone == 1            # (these shards were created under the 4-entry logs: their scans flag queries)
+    for x in shards + [bad]:
+        x.close()
