@@ -443,7 +443,8 @@ struct NextIdGuard {
 struct Geometry {
   int Lp;     // candidates kept by the approximate pass
   int C;      // per-query buffer capacity (power of two <= CAND_CAP)
-  int grow;   // chunk growth factor
+  int grow;   // chunk growth factor the plan aims at
+  int grow_max;   // largest growth the buffer takes (overflow probability <= PREDICT_EPS); >= grow
   bool predictive;
 };
 // Threshold of a chunk.  Rows are scanned in geometrically growing chunks [n0, g*n0); a chunk
@@ -513,7 +514,15 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false) {
   HX_CHECK(g.Lp * 2 <= g.C && g.Lp >= L, "limit too large");
   g.predictive = false;
   g.grow = 2;
+  g.grow_max = 2;
   if (!safe) {
+    for (int gr = 64; gr > 2; --gr) {          // what the buffer can take
+      const int kq = predict_rank(g.Lp, (double)gr);
+      if (kq < g.Lp && 1.0 - nb_cdf(kq, 1.0 / gr, g.C - g.Lp) <= PREDICT_EPS) {
+        g.grow_max = gr;
+        break;
+      }
+    }
     // (int8 candidates, L' = 450: growth 63 / 24 / 16 / 12 / 8 -> 2 / 3 / 3 / 4 / 4 launches per 10M rows, 10.69 /
     // 10.53 / 10.48 / 10.47 / 10.48 ms per step: the appended volume per launch falls with the growth)
     static const int gmax8 = getenv("HX_DEBUG_GROW_MAX8") ? std::max(3, atoi(getenv("HX_DEBUG_GROW_MAX8"))) : 16;
@@ -527,9 +536,10 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false) {
       }
     }
   }
+  g.grow_max = std::max(g.grow_max, g.grow);
   if (getenv("HX_DEBUG_GEOMETRY"))
-    fprintf(stderr, "[hx] geometry L=%d approx=%d safe=%d cand8=%d: Lp=%d C=%d grow=%d kq=%d predictive=%d\n", L, (int)approx,
-            (int)safe, (int)cand8, g.Lp, g.C, g.grow, g.predictive ? predict_rank(g.Lp, (double)g.grow) : g.Lp, (int)g.predictive);
+    fprintf(stderr, "[hx] geometry L=%d approx=%d safe=%d cand8=%d: Lp=%d C=%d grow=%d (max %d) kq=%d predictive=%d\n", L, (int)approx,
+            (int)safe, (int)cand8, g.Lp, g.C, g.grow, g.grow_max, g.predictive ? predict_rank(g.Lp, (double)g.grow) : g.Lp, (int)g.predictive);
   return cache[key] = g;
 }
 
@@ -555,6 +565,37 @@ static void zero_outputs(uint64_t* keys, int* cnt, int B, int L, hipStream_t st)
 }
 
 // scan all rows with geometric chunks; leaves the best `keep` keys (sorted) in cand
+// Ends of the chunks of a scan over n_log rows (multiples of 256; the first chunk is the buffer's capacity: every
+// row of it has its own slot).  Predictive geometries get BALANCED growth: the fewest launches the aimed-at growth
+// allows -- one fewer when a growth within 1.25 x of it (and within what the buffer takes) does it -- and then the same
+// ratio for every launch, instead of full-growth launches followed by a short last one (1.25M rows, int8 candidates:
+// 4096 -> 65k -> 1.05M -> 1.25M became 4096 -> 72k -> 1.25M; a launch costs its log scatter and a compaction whatever
+// its size).
+static std::vector<int64_t> chunk_plan(int64_t n_log, const Geometry& g) {
+  std::vector<int64_t> ends;
+  int64_t r = std::min<int64_t>(n_log, g.C);
+  ends.push_back(r);
+  if (r >= n_log) return ends;
+  double growth = (double)g.grow;
+  if (g.predictive && !getenv("HX_DEBUG_NO_BALANCE")) {
+    const double ratio = (double)n_log / (double)r;
+    int k = std::max(1, (int)std::ceil(std::log(ratio) / std::log((double)g.grow) - 1e-9));
+    if (k > 1) {
+      const double g1 = std::pow(ratio, 1.0 / (k - 1));
+      if (g1 <= 1.25 * g.grow && g1 <= (double)g.grow_max) --k;
+    }
+    growth = std::max(2.0, std::pow(ratio, 1.0 / k) * (1.0 + 1e-9));
+  }
+  while (r < n_log) {
+    // rows per launch bounded so the kernel's 32-bit tile counters cannot wrap
+    int64_t nx = std::min<int64_t>(round_up((int64_t)std::ceil((double)r * growth), 256), r + (1ll << 27));
+    if (nx >= n_log || (double)n_log / (double)nx < 1.02) nx = n_log;     // (no sliver of a last launch)
+    ends.push_back(nx);
+    r = nx;
+  }
+  return ends;
+}
+
 // int8 scans: `rinv_x` = the per-row factor of the score (f32(dot) * rinv_x[row]) * rinv_q[query], `tm` its tile maxima;
 // `prof_what` = the profile slot of the launches (hx_prof)
 static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t* Q, int64_t row_bytes, int B,
@@ -606,18 +647,14 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
     // a capacity planned for 2048 waves overflowed for half the queries).  Three times the mean, the largest launch.
     double want = 0.0;
     {
-      const int64_t tiles_all = (h->n + 255) / 256 * 256;
-      int64_t p0 = 0, p1 = std::min<int64_t>(tiles_all, g.C);
-      while (p1 < tiles_all) {
-        const int64_t nx = std::min<int64_t>(tiles_all, std::min<int64_t>(p1 * g.grow, p1 + (1ll << 27)));
+      const std::vector<int64_t> plan = chunk_plan((h->n + 255) / 256 * 256, g);
+      for (size_t i = 1; i < plan.size(); ++i) {
+        const int64_t p1 = plan[i - 1], nx = plan[i];
         const double growth = (double)nx / (double)p1;
         const double rank = g.predictive ? predict_rank(g.Lp, growth) : g.Lp;
         const double waves = std::min<double>(SCAN8_WAVES, 8.0 * (double)((nx - p1 + 255) / 256) * (double)(round_up(B, 256) / 256));
         want = std::max(want, 3.0 * rank * (growth - 1.0) * (double)B / waves + 64.0);
-        p0 = p1;
-        p1 = nx;
       }
-      (void)p0;
     }
     logcap = std::min(h->scan_logcap, std::max(256, next_pow2((int)std::min(1e9, want) + 1)));
     hitlog = (uint4*)h->ws.get(WS_HITLOG, (size_t)SCAN8_WAVES * logcap * SCAN8_ENTRY * sizeof(uint4));
@@ -641,7 +678,9 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
     a.perm_mul = (uint32_t)(m % (uint64_t)n_tiles);
     a.perm_inv = 1.0 / (double)n_tiles;
   }
-  int64_t r0 = 0, r1 = std::min<int64_t>(n_log, g.C);
+  const std::vector<int64_t> plan = chunk_plan(n_log, g);
+  size_t pi = 0;
+  int64_t r0 = 0, r1 = plan[0];
   // threshold -inf, flags 0; the first chunk passes every row into slot (row - r0): its count is known
   launch_scan_init(tau, cnt, ovf, kept, B, (int)(r1 - r0), st);
   int chk_rank = 0;   // rank whose score is the threshold of the chunk being scanned (0: none)
@@ -666,8 +705,8 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
         launch_scan(a, kind, bn, st);
       }
     }
-    // rows per launch bounded so the kernel's 32-bit tile counters cannot wrap
-    const int64_t next = std::min<int64_t>(n_log, std::min<int64_t>(r1 * g.grow, r1 + (1ll << 27)));
+    ++pi;
+    const int64_t next = pi < plan.size() ? plan[pi] : n_log;
     const int next_rank = (g.predictive && next > r1) ? predict_rank(g.Lp, (double)next / (double)r1) : g.Lp;
     launch_compact(cand, g.C, cnt, B, g.Lp, 0, cand, g.C, cnt, tau, g.C, st, next_rank, chk_rank, kept, ovf);
     chk_rank = next_rank < g.Lp ? next_rank : 0;
