@@ -83,10 +83,18 @@ def host_share():
             gpus += 1 if int(props.get("simd_count", "0")) > 0 else 0
     except OSError:
         pass
-    if gpus <= 0:
+    # The topology of a box that hands out ONE GPU of its host lists what the container may see (1 or 2 nodes on the
+    # boxes of this pool), not what the host carries.  BASELINE.json's machine is "8 x MI355X of one node": a host
+    # with the cores of such a node is taken to carry its 8 GPUs, whatever part of them is visible here.
+    try:
         import torch
-        gpus = max(torch.cuda.device_count(), 1)
-    return max(1, cores // gpus), f"{cores} usable host cores / {gpus} GPUs on the host"
+        gpus = max(gpus, torch.cuda.device_count())
+    except Exception:
+        pass
+    if cores >= 128:
+        gpus = max(gpus, 8)
+    gpus = max(gpus, 1)
+    return max(1, cores // gpus), f"{cores} usable host cores / {gpus} GPUs of the host (an MI355X node carries 8)"
 
 
 def _median3(fn):
@@ -372,7 +380,7 @@ def main():
     share, share_note = host_share()
     if args.cpu_threads > 0:
         share, share_note = args.cpu_threads, f"--cpu-threads {args.cpu_threads}"
-    os.environ.setdefault("OMP_NUM_THREADS", str(share))
+    os.environ["OMP_NUM_THREADS"] = str(share)
     import torch
     import torch.distributed as dist
     from rag_application_amd import engine as eng, synth

@@ -264,9 +264,15 @@ struct ProfScope {
     rec.bytes = bytes;
     HX_HIP(hipEventRecord(rec.a, st));
   }
+  bool ended = false;        // rec.b was recorded by the callee (launch_scan: right behind the scan kernel)
+  hipEvent_t end_event() {
+    if (!on) return nullptr;
+    ended = true;
+    return rec.b;
+  }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(rec.b, st);
+    if (!ended) (void)hipEventRecord(rec.b, st);
     h->prof_recs.push_back(rec);
   }
 };
@@ -702,7 +708,7 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
         f.nq_tiles = (int)(round_up(B, 256) / 128);
         launch_scan(f, kind, 128, st);
       } else {
-        launch_scan(a, kind, bn, st);
+        launch_scan(a, kind, bn, st, ps.end_event());
       }
     }
     ++pi;

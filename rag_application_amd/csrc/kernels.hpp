@@ -66,10 +66,11 @@ constexpr int SCAN8_LOGCAP = 4096;      // most entries per wave log (expected: 
 #define HX_S8_TS 16                     // MFMA tile side of scan8.hip: 16 (16x16x32) or 32 (32x32x16)
 #endif
 constexpr int SCAN8_ENTRY = 1 + (64 / HX_S8_TS) * (HX_S8_TS * HX_S8_TS / 64 / 4);   // 16-byte words per log entry
-void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st);
+// after_kernel (optional): recorded on `st` right behind the scan kernel itself (before scan8's log scatter)
+void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st, hipEvent_t after_kernel = nullptr);
 // scan8.hip: the 256 x 256 staggered-phase kernel behind launch_scan for large batches
 bool scan8_usable(const ScanArgs& a, int bn);
-void launch_scan8(const ScanArgs& a, int kind, hipStream_t st);   // includes the log scatter
+void launch_scan8(const ScanArgs& a, int kind, hipStream_t st, hipEvent_t after_kernel = nullptr);   // includes the log scatter
 
 // ---- select.hip --------------------------------------------------------------
 // Sort each query's buffer (first min(cnt, stride) keys) best-first, optionally drop

@@ -278,11 +278,11 @@ static void launch(const ScanArgs& a, int64_t tiles, hipStream_t st) {
   hipLaunchKernelGGL((k_scan<KIND, BM, BN, NSTAGE>), dim3((unsigned)g), dim3(BM * 2), 0, st, a);
 }
 
-void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st) {
+void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st, hipEvent_t after_kernel) {
   const int64_t n_rows = a.row_end - a.row_begin;
   if (n_rows <= 0 || a.B <= 0) return;
   HX_CHECK((a.row_bytes & 127) == 0, "scan: row_bytes must be a multiple of 128");
-  if (scan8_usable(a, bn)) return launch_scan8(a, kind, st);
+  if (scan8_usable(a, bn)) return launch_scan8(a, kind, st, after_kernel);
   const int bm = bn == 256 ? 256 : 128;
   const int64_t tiles = (n_rows + bm - 1) / bm * a.nq_tiles;
   if (kind == KIND_F16) {
@@ -297,6 +297,7 @@ void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st) {
     else launch<KIND_I8, 128, 32, 3>(a, tiles, st);
   }
   HX_HIP(hipGetLastError());
+  if (after_kernel) HX_HIP(hipEventRecord(after_kernel, st));
 }
 
 }  // namespace hx

@@ -699,7 +699,7 @@ bool scan8_usable(const ScanArgs& a, int bn) {
          a.row_bytes * 256 < (1ll << 31);
 }
 
-void launch_scan8(const ScanArgs& a, int kind, hipStream_t st) {
+void launch_scan8(const ScanArgs& a, int kind, hipStream_t st, hipEvent_t after_kernel) {
   const int64_t n_rows = a.row_end - a.row_begin;
   if (n_rows <= 0 || a.B <= 0) return;
   HX_CHECK((a.row_bytes & 127) == 0, "scan: row_bytes must be a multiple of 128");
@@ -722,6 +722,7 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st) {
   else
     hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
   HX_HIP(hipGetLastError());
+  if (after_kernel) HX_HIP(hipEventRecord(after_kernel, st));     // the profile times k_scan8 alone, not its log scatter
   const unsigned sg = (unsigned)((g + S8_SB - 1) / S8_SB) * 4;
   if (kind == KIND_F16)
     hipLaunchKernelGGL((k_scatter_log<KIND_F16, HX_S8_TS>), dim3(sg), dim3(1024), 0, st, a.hitlog, a.hitcnt, a.logcap,
