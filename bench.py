@@ -496,6 +496,33 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # N > 1, side measurement (never part of `value`): the reference's own query -- the tree -- through the sharded
+    # path: one all-gather per cascade level, the stages' flags deferred into one all-reduced word (distributed.py)
+    tree_sharded = None
+    if world > 1 and mode == "h1" and not args.no_secondary:
+        Pt = dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=60, dense_limit=40,
+                  quantized_limit=40, sparse_limit=50, final_limit=30, hnsw_ef=128)
+
+        def tree_step():
+            q, ip, ixx, vv = bcast_queries(Q, qip_d, qix_d, qv_d, src=0, device=dev, header_group=hdr_group)
+            return sh.hybrid_tree(q, ip, ixx, vv, Pt)
+
+        for _ in range(2):
+            tree_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0t = time.perf_counter()
+        nt = 5
+        for _ in range(nt):
+            tree_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0t], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tree_sharded = dict(what="reference tree (qdrant_handler.py:305-372), P-mcp limits, row-sharded: one all-gather per "
+                                 "cascade level, flags deferred (hx_search_*_async)", steps=nt,
+                            ms_per_step=float(tt.item()) / nt * 1e3, queries_per_sec=B * nt / float(tt.item()),
+                            batches_redone=int(getattr(sh, "redone", 0)))
 
     # ---- roofline of the dominant kernel (the dense stage's candidate scan), measured with HIP events ------
     use8 = prof["scan_cand8"]["launches"] > 0
@@ -591,7 +618,8 @@ def main():
                        **({"sharded_equals_single_index": verified} if verified is not None else {})},
             # recall@10 of the LAST TIMED STEP's lists against the host brute force over the whole corpus
             "recall_at_10": cpu["recall_at_10"] if cpu else None,
-            "roofline": roof, "cpu_baseline": cpu, "secondary": side,
+            "roofline": roof, "cpu_baseline": cpu,
+            "secondary": side if side is not None else ({"tree_mode_sharded": tree_sharded} if tree_sharded else None),
         }
         print(json.dumps(line), flush=True)
     ix.close()      # (idempotent: the config 4 leg may have freed it already)
