@@ -288,7 +288,8 @@ int hx_set_dense_candidates(hx_index* h, int32_t kind);
 int hx_profile(hx_index* h, int32_t enable);
 int hx_profile_read(hx_index* h, hx_prof* out);
 /* copy the derived row `row` (local) of one named vector to the host:
- * which = 0 dense f32 [dim], 1..3 prefix f32 [msizes[which-1]], 4 int8 [dim] */
+ * which = 0 dense f32 [dim], 1..3 prefix f32 [msizes[which-1]], 4 int8 [dim] (the "quantized" vector),
+ * 5 int8 [dim] the candidate-pass copy of the normalised row, 6 f32 [1] its scale */
 int hx_debug_row(hx_index* h, int32_t which, int64_t row, void* out_host);
 
 #ifdef __cplusplus

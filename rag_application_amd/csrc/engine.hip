@@ -2181,6 +2181,10 @@ int hx_debug_row(hx_index* h, int32_t which, int64_t row, void* out_host) {
     HX_HIP(hipMemcpy(out_host, h->pre[p] + row * h->psize[p], (size_t)h->psize[p] * 4, hipMemcpyDeviceToHost));
   } else if (which == 4) {
     HX_HIP(hipMemcpy(out_host, h->q8 + row * h->dim_pad8, (size_t)h->dim, hipMemcpyDeviceToHost));
+  } else if (which == 5 && h->q8s) {       // the candidate-pass copy of the row
+    HX_HIP(hipMemcpy(out_host, h->q8s + row * h->dim_pad8, (size_t)h->dim, hipMemcpyDeviceToHost));
+  } else if (which == 6 && h->q8s) {       // ... and its scale
+    HX_HIP(hipMemcpy(out_host, h->q8s_scale + row, 4, hipMemcpyDeviceToHost));
   } else {
     throw Error("bad `which`");
   }

@@ -181,8 +181,10 @@ class HxIndex:
                 for i, n in enumerate(names)}
 
     def debug_row(self, which: int, row: int) -> np.ndarray:
-        if which == 4:
+        if which in (4, 5):
             out = np.zeros(self.dim, dtype=np.int8)
+        elif which == 6:
+            out = np.zeros(1, dtype=np.float32)
         elif which == 0:
             out = np.zeros(self.dim, dtype=np.float32)
         else:

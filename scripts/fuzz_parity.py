@@ -23,6 +23,9 @@ while time.time() < t_end:
     if rng.random() < 0.3:                     # near-duplicates and planted neighbours: ties, tight gaps
         X[rng.integers(0, n, 50)] = X[rng.integers(0, n, 50)]
         X[rng.integers(0, n, min(B, 40))] = Q[: min(B, 40)] * np.float32(0.7)
+    if rng.random() < 0.2:                     # rows the int8 grid resolves badly: one dominant component each
+        rows = rng.integers(0, n, n // 10)
+        X[rows, rng.integers(0, dim, len(rows))] = np.float32(rng.uniform(5, 60))
     ix = eng.HxIndex(dim, msz)
     ip, si, sv = O.synth_sparse_docs(int(rng.integers(1, 1 << 30)), 0, n, tabs)
     ix.add(X, ip, si.astype(np.int32), sv)
@@ -30,6 +33,8 @@ while time.time() < t_end:
     # dense
     d = prefix or None
     es, ei, ec = CO.search_dense(CO.cosine_preprocess(X, d), CO.cosine_preprocess(Q, d), L)
+    kind = "f16" if rng.random() < 0.25 else "i8"   # which copy nominates the candidates of the full-vector stage
+    ix.set_dense_candidates(kind)
     s, i = eng.unpack(ix.search_dense(Qd, L, prefix)[0]); s, i = s.cpu().numpy(), i.cpu().numpy()
     for b in range(B):
         m = int(ec[b])
@@ -61,5 +66,6 @@ while time.time() < t_end:
     st = ix.stats()
     ix.close()
     n_cfg += 1; n_lists += 3 * B
-    print(f"ok dim={dim} n={n} B={B} L={L} prefix={prefix} retries={st['retry_queries']} fallbacks={st['dense_fallback_queries']}", flush=True)
+    print(f"ok dim={dim} n={n} B={B} L={L} prefix={prefix} cand={kind} retries={st['retry_queries']} fallbacks={st['dense_fallback_queries']} "
+          f"uncertified8={st['cand8_uncertified_queries']}/{st['cand8_queries']}", flush=True)
 print(f"fuzz parity: {n_cfg} configurations, {n_lists} lists, all bit-exact")

@@ -1450,3 +1450,40 @@ def test_tree_stages_deferred_flags(eng, torch_mod, synth_tables, monkeypatch):
     assert sh.redone == 1            # (these shards were created under the 4-entry logs: their scans flag queries)
     for x in shards + [bad]:
         x.close()
+
+
+def test_int8_candidate_bound_holds_pair_by_pair(eng, torch_mod):
+    """The certificate's radius, checked where it is used: for every (row, query) pair of a small collection,
+    |spec_dot(x, q) - sx sq <x8, q8>| <= (X + E_X) E_q + E_X |q| + slop, with x8 / sx read back from the index
+    (hx_debug_row 5 / 6), E_X from its stats, the query quantised by the same rule on the host -- on uniform rows, rows
+    with a dominant component, tiny rows, and rows the keep-if-unit rule leaves unnormalised."""
+    n, dim, B = 600, 768, 24
+    rng = np.random.default_rng(9)
+    X = O.synth_dense(71, 0, n, dim)
+    X[:100, rng.integers(0, dim, 100)] = 30.0                    # dominant components
+    X[100:150] *= np.float32(1e-12)                               # tiny rows (|x|^2 below FLT_EPSILON: kept as they are)
+    X[150:200] = O.cosine_preprocess(X[150:200])                  # unit rows: the keep-as-is rule
+    Q = O.synth_dense(72, 0, B, dim) * np.float32(3.0)
+    Q[0, 5] = 100.0
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    EX = ix.stats()["cand8_row_error_max"]
+    Xn = np.stack([ix.debug_row(0, r) for r in range(n)]).astype(np.float64)
+    X8 = np.stack([ix.debug_row(5, r) for r in range(n)]).astype(np.float64)
+    sx = np.array([ix.debug_row(6, r)[0] for r in range(n)], np.float64)
+    # every row's error is below the index's bound, and the bound is attained
+    ex = np.linalg.norm(Xn - sx[:, None] * X8, axis=1)
+    assert (ex <= EX * (1 + 1e-6)).all() and ex.max() >= EX * (1 - 1e-3)
+    Qn = O.cosine_preprocess(Q).astype(np.float64)
+    for b in range(B):
+        q = Qn[b]
+        qmax = np.float32(np.abs(q).max())
+        sq = np.float32(qmax / np.float32(127.0))
+        inv = np.float32(np.float32(127.0) / qmax)
+        q8 = np.clip(np.rint((q.astype(np.float32) * inv).astype(np.float32)), -127, 127).astype(np.float64)
+        Eq = np.linalg.norm(q - float(sq) * q8)
+        eps = (1.00001 + EX) * Eq + EX * np.linalg.norm(q) + (dim / 64 + 16) * 2.0 ** -24 * 1.00001 * np.linalg.norm(q)
+        s8 = (X8 @ q8) * sx * float(sq)
+        spec = np.array([O.spec_dot(Xn[r:r + 1].astype(np.float32), q.astype(np.float32))[0] for r in range(n)], np.float64)
+        assert (np.abs(spec - s8) <= eps).all(), (b, float(np.abs(spec - s8).max()), eps)
+    ix.close()
