@@ -107,7 +107,7 @@ def _median3(fn):
     return sorted(ts)[1], r
 
 
-def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000, share_note=""):
+def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000, share_note="", threads=0):
     """The C restatement of the path (oracle/hx_oracle.c, kind "port") timed on this box's host cores on a
     bounded sample: the queries `sel` of the timed batch, brute force over the WHOLE corpus (regenerated
     chunk by chunk, never resident at once).  The lists it produces are then compared -- ids and fp32 score
@@ -118,6 +118,8 @@ def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000, share_note=
     rows, mode = wl["rows"], wl["mode"]
     bs = len(sel)
     L = 100 if mode == "h1" else 10
+    if threads > 0:
+        CO.set_num_threads(threads)      # (PyTorch sets its own OpenMP thread count at import: say ours explicitly)
     threads = CO.num_threads()
     Qall = CO.synth_dense(synth.SEED_QUERY, 0, int(sel.max()) + 1, dim)
     Qn = CO.cosine_preprocess(Qall[sel])
@@ -330,7 +332,7 @@ def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, hp_h1=No
     return out
 
 
-def cfg4_shard_leg(eng, synth, torch, local, tabs, Q, sp_q, hp, B, sel, dim, check, share_note):
+def cfg4_shard_leg(eng, synth, torch, local, tabs, Q, sp_q, hp, B, sel, dim, check, share_note, share=0):
     """BASELINE config 4 = 100M x 768 row-sharded over 8 GPUs = 12.5M rows per GPU.  One such shard (rank 0's: rows
     [0, 12.5M) of the same generator, with its postings) on this one GPU: the H1 step every rank would run before the
     exchange, its lists brute-forced on the host like the main workload's."""
@@ -366,7 +368,7 @@ def cfg4_shard_leg(eng, synth, torch, local, tabs, Q, sp_q, hp, B, sel, dim, che
             gs, gi = eng.unpack(res[0])
             res_np = (gs.cpu().numpy(), gi.cpu().numpy(), res[1].cpu().numpy())
             wl = dict(rows=rows, mode="h1", batch=B)
-            cb = cpu_baseline(wl, sel, dim, tabs, res_np, share_note=share_note)
+            cb = cpu_baseline(wl, sel, dim, tabs, res_np, share_note=share_note, threads=share)
             out.update(parity_on_sample=cb["parity_on_sample"], recall_at_10=cb["recall_at_10"], checked=cb["checked"],
                        cpu_queries_per_sec=cb["value"], sample=cb["sample"])
         ix.close()
@@ -581,7 +583,7 @@ def main():
         if not args.no_cpu_baseline:      # (before the side measurements: they end with this index freed)
             gs, gi = eng.unpack(res[0])
             res_np = (gs.cpu().numpy(), gi.cpu().numpy(), res[1].cpu().numpy())
-            cpu = cpu_baseline(wl, sel, dim, tabs, res_np, share_note=share_note)
+            cpu = cpu_baseline(wl, sel, dim, tabs, res_np, share_note=share_note, threads=share)
         if not args.no_secondary:
             hp_tree = eng.make_params(P, mode=eng.HX_MODE_TREE)
             side = secondary(eng, synth, torch, ix, wl, tabs, Q, (qip_d, qix_d, qv_d) if mode == "h1" else None,
@@ -591,7 +593,7 @@ def main():
                 # BASELINE config 4's per-GPU shape on this one GPU: the 10M index is freed first
                 ix.close()
                 side["cfg4_shard"] = cfg4_shard_leg(eng, synth, torch, local, tabs, Q, (qip_d, qix_d, qv_d), hp, B, sel,
-                                                    dim, not args.no_cpu_baseline, share_note)
+                                                    dim, not args.no_cpu_baseline, share_note, share)
 
     if rank == 0:
         st = st_main

@@ -42,6 +42,10 @@ def num_threads() -> int:
     return lib().ho_num_threads()
 
 
+def set_num_threads(n: int) -> None:
+    lib().ho_set_num_threads(int(n))
+
+
 def spec_dot(x, q) -> float:
     x = np.ascontiguousarray(x, F32)
     q = np.ascontiguousarray(q, F32)

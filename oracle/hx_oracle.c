@@ -146,6 +146,15 @@ static int n_threads(void) {
 #endif
 }
 int ho_num_threads(void) { return n_threads(); }
+/* the timed baseline runs on a stated number of host threads (bench.py: the box share of one GPU) whatever another
+ * OpenMP user of the process (PyTorch) set before */
+void ho_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 /* Xn [n x d] normalised rows, Qn [B x d] normalised queries */
 void ho_search_dense(const float* Xn, int64_t n, int d, const float* Qn, int B, int L, int64_t id_base,
