@@ -634,13 +634,14 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 // places the keys with LDS atomics.
 constexpr int S8_SB = 8;
 template <int KIND, int TS>
-__global__ __launch_bounds__(1024) void k_scatter_log(const uint4* __restrict__ log, const int* __restrict__ hitcnt,
+__global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __restrict__ hitcnt,
                                                       int logcap, int n_scan_blocks, int nq_tiles,
                                                       const float* __restrict__ tau, int64_t row_end, int64_t id_base,
                                                       const float* __restrict__ rinv_x, const float* __restrict__ rinv_q,
                                                       uint64_t* __restrict__ cand, int* __restrict__ cnt,
                                                       int* __restrict__ ovf, int cap) {
   constexpr int MT = 64 / TS, EPT = TS * TS / 64, NG = EPT / 4, ENTRY = 1 + MT * NG;
+  static_assert(MT * NG * 4 <= 32, "one mask bit per logged score");
   __shared__ int lcnt[S8_MAXQ / 4];    // per query of the column group: candidates, then next slot
   const int tid = threadIdx.x;
   const int wn = blockIdx.x & 3;                      // query column group
@@ -654,52 +655,71 @@ __global__ __launch_bounds__(1024) void k_scatter_log(const uint4* __restrict__ 
   const int w = sb * 8 + (l & 1) * 4 + wn;            // waves wn and wn + 4 of the scan workgroup
   int n = sb < n_scan_blocks ? hitcnt[w] : 0;
   n = n < logcap ? n : logcap;
-  const uint4* base = log + (int64_t)w * logcap * ENTRY;
-  for (int pass = 0; pass < 2; ++pass) {
-    {
-      for (int i = lane; i < n; i += 64) {
-        const uint4* e = base + (int64_t)i * ENTRY;
-        const uint4 h = e[0];
-        const int q = (int)h.x;
-        const int loc = (q >> 8) * 64 + (q & 63);
-        const int64_t row0 = (int64_t)(((uint64_t)h.z << 32) | h.y);
-        const float t = tau[q];
-        float rq = 0.f;
-        if constexpr (KIND == KIND_I8) rq = rinv_q[q];
+  uint4* base = log + (int64_t)w * logcap * ENTRY;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  // exact score of logged element (mt, g, k) of an entry: fp16 the score itself, int8 the oracle's (f32(dot) * rinv_x) * rinv_q
+  // Pass 0 scores all 16 elements of an entry (four consecutive rows per word: their scales come as one 16-byte load,
+  // not four gathers), counts the passing ones with ONE LDS atomic per entry and leaves their bit mask in the
+  // entry's spare header word; pass 1 -- after the workgroup reserved a range per query -- touches only entries with a
+  // mask and only their passing elements (about one of sixteen), with one LDS atomic per entry again.
+  for (int i = lane; i < n; i += 64) {
+    uint4* e = base + (int64_t)i * ENTRY;
+    const uint4 h = e[0];
+    const int q = (int)h.x;
+    const int64_t row0 = (int64_t)(((uint64_t)h.z << 32) | h.y);
+    const float t = tau[q];
+    float rq = 0.f;
+    if constexpr (KIND == KIND_I8) rq = rinv_q[q];
+    uint32_t mask = 0;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const uint4 v = e[1 + mt * NG + g];
-            const uint32_t bits[4] = {v.x, v.y, v.z, v.w};
+      for (int g = 0; g < NG; ++g) {
+        const uint4 v = e[1 + mt * NG + g];
+        const uint32_t bits[4] = {v.x, v.y, v.z, v.w};
+        const int64_t r4 = row0 + mt * TS + 8 * g;    // multiple of 4: the four scales are one aligned load
+        f4 sc = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (KIND == KIND_I8) sc = *(const f4*)(rinv_x + r4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int64_t row = row0 + mt * TS + 8 * g + k;
-              if (row >= row_end) continue;
-              float s;
-              if constexpr (KIND == KIND_F16) s = __builtin_bit_cast(float, bits[k]);
-              else s = __fmul_rn(__fmul_rn((float)(int)bits[k], rinv_x[row]), rq);   // the oracle's int8 score
-              if (s >= t) {
-                const int pos = atomicAdd(&lcnt[loc], 1);   // pass 0: count; pass 1: global slot
-                if (pass == 1) {
-                  if (pos < cap)
-                    cand[(int64_t)q * cap + pos] = make_key(s, (uint32_t)(id_base + row));
-                  else
-                    ovf[q] = 1;
-                }
-              }
-            }
-          }
+        for (int k = 0; k < 4; ++k) {
+          float s;
+          if constexpr (KIND == KIND_F16) s = __builtin_bit_cast(float, bits[k]);
+          else s = __fmul_rn(__fmul_rn((float)(int)bits[k], sc[k]), rq);
+          if (r4 + k < row_end && s >= t) mask |= 1u << ((mt * NG + g) * 4 + k);
+        }
       }
-    }
-    __syncthreads();
-    if (pass == 0) {
-      for (int i = tid; i < nloc; i += 1024) {
-        const int c = lcnt[i];
-        const int q = (i >> 6) * 256 + wn * 64 + (i & 63);
-        lcnt[i] = c > 0 ? atomicAdd(cnt + q, c) : 0;   // first slot of this workgroup's range
-      }
-      __syncthreads();
+    ((uint32_t*)e)[3] = mask;
+    if (mask) atomicAdd(&lcnt[(q >> 8) * 64 + (q & 63)], __builtin_popcount(mask));
+  }
+  __syncthreads();
+  for (int i = tid; i < nloc; i += 1024) {
+    const int c = lcnt[i];
+    const int q = (i >> 6) * 256 + wn * 64 + (i & 63);
+    lcnt[i] = c > 0 ? atomicAdd(cnt + q, c) : 0;   // first slot of this workgroup's range
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {
+    const uint4* e = base + (int64_t)i * ENTRY;
+    const uint4 h = e[0];                          // (its mask word was written by this very lane above)
+    uint32_t mask = h.w;
+    if (!mask) continue;
+    const int q = (int)h.x;
+    const int64_t row0 = (int64_t)(((uint64_t)h.z << 32) | h.y);
+    float rq = 0.f;
+    if constexpr (KIND == KIND_I8) rq = rinv_q[q];
+    int pos = atomicAdd(&lcnt[(q >> 8) * 64 + (q & 63)], __builtin_popcount(mask));
+    while (mask) {
+      const int bit = __builtin_ctz(mask);
+      mask &= mask - 1;
+      const int word = bit >> 2, k = bit & 3;      // word = mt * NG + g
+      const int64_t row = row0 + (word / NG) * TS + 8 * (word % NG) + k;
+      const uint32_t raw = ((const uint32_t*)(e + 1 + word))[k];
+      float s;
+      if constexpr (KIND == KIND_F16) s = __builtin_bit_cast(float, raw);
+      else s = __fmul_rn(__fmul_rn((float)(int)raw, rinv_x[row]), rq);   // the oracle's int8 score, as in pass 0
+      if (pos < cap) cand[(int64_t)q * cap + pos] = make_key(s, (uint32_t)(id_base + row));
+      else ovf[q] = 1;
+      ++pos;
     }
   }
 }
