@@ -509,22 +509,25 @@ def main():
             q, ip, ixx, vv = bcast_queries(Q, qip_d, qix_d, qv_d, src=0, device=dev, header_group=hdr_group)
             return sh.hybrid_tree(q, ip, ixx, vv, Pt)
 
-        for _ in range(2):
-            tree_step()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0t = time.perf_counter()
-        nt = 5
-        for _ in range(nt):
-            tree_step()
-        torch.cuda.synchronize()
-        dist.barrier()
-        tt = torch.tensor([time.perf_counter() - t0t], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        tree_sharded = dict(what="reference tree (qdrant_handler.py:305-372), P-mcp limits, row-sharded: one all-gather per "
-                                 "cascade level, flags deferred (hx_search_*_async)", steps=nt,
-                            ms_per_step=float(tt.item()) / nt * 1e3, queries_per_sec=B * nt / float(tt.item()),
-                            batches_redone=int(getattr(sh, "redone", 0)))
+        try:        # (a failure here must not cost the line its main measurement, which is complete at this point)
+            for _ in range(2):
+                tree_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0t = time.perf_counter()
+            nt = 5
+            for _ in range(nt):
+                tree_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t0t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tree_sharded = dict(what="reference tree (qdrant_handler.py:305-372), P-mcp limits, row-sharded: one all-gather "
+                                     "per cascade level, flags deferred (hx_search_*_async)", steps=nt,
+                                ms_per_step=float(tt.item()) / nt * 1e3, queries_per_sec=B * nt / float(tt.item()),
+                                batches_redone=int(getattr(sh, "redone", 0)))
+        except Exception as e:
+            tree_sharded = dict(error=repr(e)[:300])
 
     # ---- roofline of the dominant kernel (the dense stage's candidate scan), measured with HIP events ------
     use8 = prof["scan_cand8"]["launches"] > 0

@@ -38,6 +38,15 @@ __device__ __forceinline__ bool keep_unnormalised(float len2) {
 }
 
 constexpr int MAXCH = 64;  // dim <= 4096
+// the derived copies of a row are written once and read by later kernels only: streaming stores (HX_PREP_NT=0: plain)
+#ifndef HX_PREP_NT
+#define HX_PREP_NT 1
+#endif
+#if HX_PREP_NT
+#define HX_NT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define HX_NT_STORE(ptr, val) (*(ptr) = (val))
+#endif
 
 // Candidate-pass copy (DESIGN.md "int8 candidate pass"): the NORMALISED row scaled to its own range,
 // x8 = rint(x * 127 / max|x|) with sx = max|x| / 127 stored beside it, and the quantisation error
@@ -124,8 +133,8 @@ __global__ __launch_bounds__(256) void k_prep_rows(PrepRowsArgs a) {
       f4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = keep[0] ? v[e] : div_f32_rn(v[e], ln[0]);
-      *(f4*)(d32 + c) = o;
-      *(h4*)(d16 + c) = h4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+      HX_NT_STORE((f4*)(d32 + c), o);
+      HX_NT_STORE((h4*)(d16 + c), (h4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]}));
       if (ds8) {
         uint32_t pk = 0;
 #pragma unroll
@@ -135,16 +144,16 @@ __global__ __launch_bounds__(256) void k_prep_rows(PrepRowsArgs a) {
           const double de = (double)o[e] - (double)sx * (double)t;
           err2 += de * de;
         }
-        *(uint32_t*)(ds8 + c) = pk;
+        HX_NT_STORE((uint32_t*)(ds8 + c), pk);
       }
       for (int k = 0; k < a.n_prefix; ++k) {
         if (c >= a.psize[k]) continue;
         f4 po;
 #pragma unroll
         for (int e = 0; e < 4; ++e) po[e] = keep[1 + k] ? v[e] : div_f32_rn(v[e], ln[1 + k]);
-        *(f4*)(a.pre[k] + row * a.psize[k] + c) = po;
+        HX_NT_STORE((f4*)(a.pre[k] + row * a.psize[k] + c), po);
         if (k == 0 && a.pre_h0)
-          *(h4*)(a.pre_h0 + row * a.psize[0] + c) = h4{(_Float16)po[0], (_Float16)po[1], (_Float16)po[2], (_Float16)po[3]};
+          HX_NT_STORE((h4*)(a.pre_h0 + row * a.psize[0] + c), (h4{(_Float16)po[0], (_Float16)po[1], (_Float16)po[2], (_Float16)po[3]}));
       }
     } else if (ds8) {
       *(uint32_t*)(ds8 + c) = 0u;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256) void k_prep_rows(PrepRowsArgs a) {
       pk |= (uint32_t)(uint8_t)t << (8 * e);
       n2 += (int)t * (int)t;
     }
-    *(uint32_t*)(d8 + c) = pk;
+    HX_NT_STORE((uint32_t*)(d8 + c), pk);
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
