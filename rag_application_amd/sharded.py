@@ -138,11 +138,14 @@ class ShardedCollection:
     host-side control group (made here when not given)."""
 
     def __init__(self, dim: int = 768, msizes: Sequence[int] = (64, 128, 256), group=None, index_factory=None,
-                 ops=None, src: int = 0, ctl=None, local=None, counts=None):
+                 ops=None, src: int = 0, ctl=None, local=None, counts=None, device: Optional[torch.device] = None):
         self.dim, self.msizes, self.group, self.src = int(dim), tuple(msizes), group, src
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.dev = _dev_of(group)
+        # `dev`: where this rank's shard lives and the stages run; `cdev`: where the collectives run (the device for
+        # RCCL, the host for gloo -- rehearsals and tests, also with real shards on a GPU: device=cuda over a gloo group)
+        self.cdev = _dev_of(group)
+        self.dev = device if device is not None else self.cdev
         self.ctl = ctl if ctl is not None else _control_group(group)
         if local is None:
             if index_factory is None:
@@ -264,10 +267,10 @@ class ShardedCollection:
                 ix_t, v_t = torch.as_tensor(np.asarray(ix, np.int32)), torch.as_tensor(np.asarray(v, np.float32))
             nnzs = [int(ip[cut[j + 1]] - ip[cut[j]]) if has_sp else 0 for j in range(W)]
         nnz = self._bcast_obj(nnzs)[r]                                      # nnz of the rank's block
-        my_d = torch.empty((m, self.dim), dtype=torch.float32, device=self.dev)
-        my_ip = torch.empty(m + 1, dtype=torch.int64, device=self.dev)
-        my_ix = torch.empty(nnz, dtype=torch.int32, device=self.dev)
-        my_v = torch.empty(nnz, dtype=torch.float32, device=self.dev)
+        my_d = torch.empty((m, self.dim), dtype=torch.float32, device=self.cdev)
+        my_ip = torch.empty(m + 1, dtype=torch.int64, device=self.cdev)
+        my_ix = torch.empty(nnz, dtype=torch.int32, device=self.cdev)
+        my_v = torch.empty(nnz, dtype=torch.float32, device=self.cdev)
         if r == self.src:
             reqs = []
             for j in range(W):
@@ -279,7 +282,7 @@ class ShardedCollection:
                     for dst, p in zip((my_d, my_ip, my_ix, my_v), parts):
                         dst.copy_(p)
                 else:
-                    reqs += [dist.isend(p.contiguous().to(self.dev), j, group=self.group) for p in parts if p.numel()]
+                    reqs += [dist.isend(p.contiguous().to(self.cdev), j, group=self.group) for p in parts if p.numel()]
             for q in reqs:
                 q.wait()
         else:
@@ -423,10 +426,11 @@ class ShardedHandler(QdrantHandler):
 
     def __init__(self, group=None, index_factory=None, ops=None, src: int = 0, dense_vector_size: int = 768,
                  matryoshka_sizes: Sequence[int] = (64, 128, 256), reranker=None, persist_dir: Optional[str] = None,
-                 timeout: float = 300.0, index_loader=None):
+                 timeout: float = 300.0, index_loader=None, device: Optional[torch.device] = None):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        dev = _dev_of(group)
+        dev = device if device is not None else _dev_of(group)
+        self.shard_device = device
         super().__init__(reranker=reranker, device=dev.index or 0, persist_dir=persist_dir)
         self.factory, self.loader, self.ops, self.src = index_factory, index_loader, ops, src
         self.dim, self.msizes = int(dense_vector_size), tuple(matryoshka_sizes)
@@ -447,7 +451,7 @@ class ShardedHandler(QdrantHandler):
             raise ShardError(self.broken)
         if self.world == 1:
             return op, user_id, meta
-        if self.dev_is_cuda():
+        if self.dev_is_cuda() or (self.shard_device is not None and self.shard_device.type == "cuda"):
             torch.cuda.set_device(self.device)       # executor threads start on device 0
         try:
             box = [op, user_id, meta] if self.rank == self.src else [None, None, None]
@@ -544,7 +548,7 @@ class ShardedHandler(QdrantHandler):
                     local.close()
                 raise ShardError("stored collection not loaded: " + "; ".join(bad))
         col = ShardedCollection(dim, msizes, self.group, self.factory, self.ops, self.src, ctl=self.ctl, local=local,
-                                counts=counts if load else None)
+                                counts=counts if load else None, device=self.shard_device)
         self._shards[user_id] = col
         return col
 

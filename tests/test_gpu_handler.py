@@ -234,3 +234,122 @@ def test_local_hf_encoder_on_the_gpu_feeds_the_index(tmp_path):
         np.testing.assert_array_equal(s[b].view(np.uint32), es.view(np.uint32))
         assert i[b, 0] == b
     ix.close()
+
+
+# ---- the sharded handler with REAL shards: two ranks share the GPU, collectives over gloo ----------------------------------
+def _sharded_real_worker(rank, world, port, n, dim, B, ret):
+    import os
+    import socket  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as OO
+    from rag_application_amd import engine as eng
+    from rag_application_amd.sharded import ShardedHandler, ShardError
+    made = []
+
+    class Shard(eng.HxIndex):                      # the real engine; rank 1's third shard refuses its second block
+        fail_adds = ()
+
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            self.n_add = 0
+
+        def add(self, *a, **kw):
+            k, self.n_add = self.n_add, self.n_add + 1
+            if k in self.fail_adds:
+                raise RuntimeError("shard refuses the block")
+            return super().add(*a, **kw)
+
+    def factory(d, ms, base):
+        sh = Shard(d, ms, device=0, id_base=base)
+        made.append(sh)
+        if rank == 1 and len(made) == 2:
+            sh.fail_adds = (1,)
+        return sh
+
+    h = ShardedHandler(index_factory=factory, dense_vector_size=dim, matryoshka_sizes=(64,), timeout=120,
+                       device=torch.device("cuda", 0))
+    if rank != 0:
+        h.serve()
+    else:
+        tabs = OO.synth_tables()
+        X = OO.synth_dense(OO.SEED_CORPUS, 0, n, dim)
+        X[n // 2 + 7] = X[3]                        # a tie across batches and shards
+        ip, si, sv = OO.synth_sparse_docs(OO.SEED_SPDOC, 0, n, tabs)
+        chunks = [{"content": f"chunk {r}", "dense_embedding": X[r].tolist(),
+                   "sparse_embedding": {"indices": si[ip[r]:ip[r + 1]].tolist(), "values": sv[ip[r]:ip[r + 1]].tolist()},
+                   "chunk_metadata": {"document_id": "d", "user_id": "u", "file_name": f"f{r % 3}.txt", "mime_type": "t",
+                                      "file_size": 1, "description": "", "file_path": "/p", "context_version": 1,
+                                      "chunk_number": r, "doc_summary": "s"}} for r in range(n)]
+        Q = OO.synth_dense(OO.SEED_QUERY, 0, B, dim)
+        Q[0] = X[3]
+        qip, qsi, qsv = OO.synth_sparse_queries(OO.SEED_SPQUERY, 0, B, tabs)
+        sp = [{"indices": qsi[qip[b]:qip[b + 1]].tolist(), "values": qsv[qip[b]:qip[b + 1]].tolist()} for b in range(B)]
+        P = dict(matryoshka_64_limit=60, matryoshka_128_limit=1, matryoshka_256_limit=1, dense_limit=30,
+                 quantized_limit=30, sparse_limit=25, final_limit=12, hnsw_ef=1)
+        c1, c2 = n // 2 + 1, n // 2 + n // 7 + 2
+        for a, b in ((0, c1), (c1, c2), (c2, n)):
+            run(h.store_document_vectors(chunks[a:b], "u"))
+        tree = run(h.hybrid_search_batch("u", Q.tolist(), sp, top_k=12, search_params=P))
+        h1 = run(h.hybrid_search_batch("u", Q.tolist(), sp, top_k=10, search_params=P, mode="h1"))
+        ret["tree"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in tree]
+        ret["h1"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in h1]
+        # a shard that refuses a block: every rank rolls back (hx_truncate on this rank's real shard), then the batch goes in
+        run(h.store_document_vectors(chunks[:400], "w"))
+        try:
+            run(h.store_document_vectors(chunks[400:700], "w"))
+            ret["rolled"] = "no error"
+        except ShardError:
+            ret["rolled"] = (run(h.get_collection_chunk_count("w")), made[-1].count())
+        run(h.store_document_vectors(chunks[400:700], "w"))
+        hw = run(h.hybrid_search_batch("w", Q.tolist(), sp, top_k=10, search_params=P, mode="h1"))
+        ret["h1w"] = [[(p.payload["chunk_number"], p.score) for p in row] for row in hw]
+        run(h.delete_collection("w"))
+        run(h.delete_collection("u"))
+        h.shutdown()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_handler_real_shards_two_ranks_one_gpu():
+    """ShardedHandler over REAL engine shards: two processes share the GPU, collectives over gloo.  Three uneven batches
+    (insertion-order ids through hx_set_next_id), tree + H1 equal the unsharded oracle -- ids and score bits, a tie across
+    batches and shards included; a shard that refuses its block makes the store raise and the other shard roll its block
+    back (hx_truncate); the same batch then goes in."""
+    import socket
+    import torch.multiprocessing as mp
+    n, dim, B = 3000, 128, 6
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_real_worker, args=(2, port, n, dim, B, ret), nprocs=2, join=True)
+    tabs = O.synth_tables()
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    X[n // 2 + 7] = X[3]
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
+    full = O.OracleIndex(dim, (64,))
+    full.add(X, ip, si, sv)
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    Q[0] = X[3]
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, tabs)
+    P = dict(matryoshka_64_limit=60, matryoshka_128_limit=1, matryoshka_256_limit=1, dense_limit=30,
+             quantized_limit=30, sparse_limit=25, final_limit=12, hnsw_ef=1)
+    w = O.OracleIndex(dim, (64,))
+    w.add(X[:700], ip[:701], si[:ip[700]], sv[:ip[700]])
+    assert ret["rolled"] == (400, 200)
+    for b in range(B):
+        q = (qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]])
+        es, ei = O.hybrid_tree(full, Q[b], *q, P)
+        assert [t[0] for t in ret["tree"][b]] == ei.tolist()
+        np.testing.assert_array_equal(np.array([t[1] for t in ret["tree"][b]], np.float32).view(np.uint32), es.view(np.uint32))
+        es, ei = O.hybrid_h1(full, Q[b], *q, 30, 25, 12)
+        assert [t[0] for t in ret["h1"][b]] == ei[:10].tolist()
+        np.testing.assert_array_equal(np.array([t[1] for t in ret["h1"][b]], np.float32).view(np.uint32), es[:10].view(np.uint32))
+        es, ei = O.hybrid_h1(w, Q[b], *q, 30, 25, 12)
+        assert [t[0] for t in ret["h1w"][b]] == ei[:10].tolist()
+    assert 3 in [t[0] for t in ret["tree"][0][:2]] and n // 2 + 7 in [t[0] for t in ret["tree"][0][:2]]
