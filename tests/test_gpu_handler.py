@@ -309,6 +309,42 @@ def _sharded_real_worker(rank, world, port, n, dim, B, ret):
         run(h.delete_collection("w"))
         run(h.delete_collection("u"))
         h.shutdown()
+    # -- BASELINE config 5's shape with the real engine: TEXT chunks dealt to the ranks, every rank encodes its own block
+    # on the GPU (an encoder replica per rank: here a stand-in that leaves its vectors on the device), the BM25 provider
+    # on its host cores, and the block goes into the rank's shard where it lies (hx_add_rows_dev) under its insertion ids
+    from rag_application_amd import bm25
+    from rag_application_amd.sharded import ShardedCollection
+    words = "vector search engine retrieval hybrid dense sparse index document chunk query ranking fusion kernel".split()
+
+    def text_of(r):
+        g = np.random.default_rng(1000 + r)
+        return " ".join(g.choice(words, size=int(g.integers(4, 20))))
+
+    class Enc:
+        def encode(self, texts):
+            rows = [int(t.split("|")[0]) for t in texts]
+            return torch.from_numpy(np.stack([OO.synth_dense(900, r, 1, dim)[0] for r in rows])).cuda()
+
+    def sparse_embed(texts):
+        ip_, ix_, v_ = bm25.embed_batch_csr([t.split("|", 1)[1] for t in texts])
+        return ip_, ix_.astype(np.int32), v_.astype(np.float32)
+
+    col = ShardedCollection(dim, (64,), device=torch.device("cuda", 0))
+    texts = [f"{r}|{text_of(r)}" for r in range(301)]
+    for a, b in ((0, 120), (120, 301)):
+        col.store(texts=texts[a:b] if rank == 0 else None, encoder=Enc(), sparse_embed=sparse_embed)
+    assert col.count() == 301 and col.local.count() in (150, 151)
+    Qt = OO.synth_dense(OO.SEED_QUERY, 0, 3, dim)
+    qsp = [bm25.embed("hybrid dense retrieval engine"), bm25.embed("sparse index query"), bm25.embed("kernel")]
+    if rank == 0:
+        qi = np.concatenate([np.sort(np.asarray(i_, np.int64)) for i_, _ in qsp])
+        qv_ = np.concatenate([np.asarray(v_, np.float32)[np.argsort(np.asarray(i_, np.int64))] for i_, v_ in qsp])
+        qp = np.cumsum([0] + [len(i_) for i_, _ in qsp])
+        k, c = col.search(Qt, qp, qi.astype(np.int32), qv_, dict(dense_limit=20, sparse_limit=20, final_limit=10), "h1")
+        ret["texts"] = col.resolve(k, c)
+    else:
+        col.search()
+    col.close()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -353,3 +389,22 @@ def test_sharded_handler_real_shards_two_ranks_one_gpu():
         es, ei = O.hybrid_h1(w, Q[b], *q, 30, 25, 12)
         assert [t[0] for t in ret["h1w"][b]] == ei[:10].tolist()
     assert 3 in [t[0] for t in ret["tree"][0][:2]] and n // 2 + 7 in [t[0] for t in ret["tree"][0][:2]]
+    # the text ingest: row r = encoder output synth_dense(900, r) + the BM25 vector of its text, in insertion order
+    from rag_application_amd import bm25
+    words = "vector search engine retrieval hybrid dense sparse index document chunk query ranking fusion kernel".split()
+    enc = O.OracleIndex(dim, (64,))
+    rows, tip, tix, tv = [], [0], [], []
+    for r in range(301):
+        g = np.random.default_rng(1000 + r)
+        i_, v_ = bm25.embed(" ".join(g.choice(words, size=int(g.integers(4, 20)))))
+        rows.append(O.synth_dense(900, r, 1, dim)[0])
+        tix += list(i_)
+        tv += list(v_)
+        tip.append(len(tix))
+    enc.add(np.stack(rows), np.asarray(tip, np.int64), np.asarray(tix, np.int64), np.asarray(tv, np.float32))
+    Qt = O.synth_dense(O.SEED_QUERY, 0, 3, dim)
+    for b, text in enumerate(("hybrid dense retrieval engine", "sparse index query", "kernel")):
+        i_, v_ = bm25.embed(text)
+        es, ei = O.hybrid_h1(enc, Qt[b], np.asarray(i_, np.int64), np.asarray(v_, np.float32), 20, 20, 10)
+        assert [t[0] for t in ret["texts"][b]] == ei.tolist(), (b, ret["texts"][b], ei)
+        np.testing.assert_array_equal(np.array([t[1] for t in ret["texts"][b]], np.float32).view(np.uint32), es.view(np.uint32))
