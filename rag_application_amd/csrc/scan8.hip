@@ -65,6 +65,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef HX_S8_PH
 #define HX_S8_PH 2   // phases per k-tile: 4 (one quadrant each) or 2 (two quadrants each)
 #endif
+#ifndef HX_S8_PRIO
+#define HX_S8_PRIO 1   // 1: raise the wave's priority for its M segment; 0: never; 2: waves 4..7 at priority 1 throughout
+#endif
 constexpr int S8_HT = 16384;       // half-tile bytes
 constexpr int S8_MAXQ = 4096;      // queries whose thresholds fit the LDS table
 
@@ -77,6 +80,15 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   constexpr int KS = TS == 32 ? 4 : 2; // MFMA k-steps of a k-tile
   constexpr int EPT = TS * TS / 64;    // accumulator registers of one tile
   constexpr int AUX = S8_MAXQ * 4;
+  // timing builds (wrong results; -DHX_SCAN_DBG, scripts/scan8_ablate.sh): 1 one corpus tile over and over, 2 no loads in the
+  // loop, 3 no MFMAs, 4 no filter, 5 no fragment reads in the loop, 6 neither loads nor reads nor filter (MFMAs + barriers),
+  // 7 as 6 without the barriers, 8 no loads and no filter, 9 / 10 below
+  constexpr bool NO_READS = DBG == 5 || DBG == 6 || DBG == 7;
+  constexpr bool NO_GLDS = DBG == 2 || DBG == 6 || DBG == 7 || DBG == 8;
+  constexpr bool NO_FILTER = DBG == 4 || DBG == 6 || DBG == 7 || DBG == 8 || DBG == 9 || DBG == 10;
+  constexpr bool NO_VMWAIT = DBG == 9;     // 9: no filter and no counted waits (the loads are issued, nothing waits for them)
+  constexpr bool ONE_TILE = DBG == 1 || DBG == 10;   // 10: 1 without the filter
+  constexpr bool NO_BAR = DBG == 7;
   __shared__ __attribute__((aligned(1024))) uint8_t lds[8 * S8_HT + AUX];
   float* lds_tau = (float*)(lds + 8 * S8_HT);
 
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   };
   auto tile_ptrs = [&](int j, Cur& c) __attribute__((always_inline)) {
     const int d = __builtin_amdgcn_readfirstlane(j / nq);   // keep the cursor in scalar registers
-    const int rt = DBG == 1 ? 0 : d * 8 + xcd, qt = j - d * nq;
+    const int rt = ONE_TILE ? 0 : d * 8 + xcd, qt = j - d * nq;
     c.a = a.A + (int64_t)phys_tile(rt) * 256 * a.row_bytes;
     c.q = a.Q + (int64_t)qt * 256 * a.row_bytes;
   };
@@ -182,8 +194,13 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   };
   bool in_loop = false;
   auto stage1 = [&](const uint8_t* base, int koff, const uint32_t (&off)[2], int slot, int c) __attribute__((always_inline)) {
-    if (DBG == 2 && in_loop) return;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(base + koff + off[c]),
+    if (NO_GLDS && in_loop) return;
+    // (the empty asm keeps the zero-extension of the lane offset in this block: hoisted out of the loop as a 64-bit pair,
+    // instruction selection no longer sees `scalar base + zext(32-bit lane offset)` and falls back to a 64-bit VALU add
+    // per piece into ONE temporary pair -- a VALU->VMEM->VALU chain in the L segment -- instead of the saddr form)
+    uint32_t o = off[c];
+    asm volatile("" : "+v"(o));
+    __builtin_amdgcn_global_load_lds(GLB_PTR(base + koff + o),
                                      LDS_PTR(lds + slot * S8_HT + (wave + 8 * c) * 1024), 16, 0, 0);
   };
   auto stage = [&](const uint8_t* base, int koff, const uint32_t (&off)[2], int slot) __attribute__((always_inline)) {
@@ -200,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   frag_t bA[NT][KS], bB[NT][KS];  // query fragments: B0 / B1 alternate between the two sets
 
   auto read_a = [&](int slot) __attribute__((always_inline)) {
+    if (NO_READS && in_loop) return;
     const uint8_t* s = lds + slot * S8_HT;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -207,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
       for (int ks = 0; ks < KS; ++ks) af[mt][ks] = *(const frag_t*)(s + rdA[ks] + mt * (TS * 128));
   };
   auto read_b = [&](int slot, frag_t (&b)[NT][KS]) __attribute__((always_inline)) {
+    if (NO_READS && in_loop) return;
     const uint8_t* s = lds + slot * S8_HT;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -233,9 +252,17 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   read_b(1, bA);
 #endif
   if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger
+  if (NO_READS) {
+    read_a(0);
+    read_b(1, bA);
+    read_b(2, bB);
+  }
 
   int cj = i0, c_kt = 0;
   in_loop = true;
+#if HX_S8_PRIO == 2
+  if (wm == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
   // quadrant epilogue: threshold filter; passing (key, query) pairs go to this wave's log
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -267,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     }
   };
   auto filter = [&](int rt, int qt, int ha, int hb, acc_t (&c)[MT][NT]) __attribute__((always_inline)) {
-    if constexpr (DBG == 4) {        // timing build: no filter at all (the accumulators are kept alive)
+    if constexpr (NO_FILTER) {       // timing build: no filter at all (the accumulators are kept alive)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -496,15 +523,15 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   }                                                                             \
   if (HX_S8_FILTER_IN_M == 1 && __builtin_expect(last, 0)) filter(rt, qt, HA, HB, ACC);
 #define S8_L_END(N)                                                             \
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                      \
+  if (!NO_VMWAIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");      \
   __builtin_amdgcn_sched_barrier(0);                                            \
-  __builtin_amdgcn_s_barrier();                                                 \
+  if (!NO_BAR) __builtin_amdgcn_s_barrier();                                    \
   __builtin_amdgcn_sched_barrier(0);                                            \
-  __builtin_amdgcn_s_setprio(1);
+  if (HX_S8_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #define S8_M_END()                                                              \
-  __builtin_amdgcn_s_setprio(0);                                                \
+  if (HX_S8_PRIO == 1) __builtin_amdgcn_s_setprio(0);                           \
   __builtin_amdgcn_sched_barrier(0);                                            \
-  __builtin_amdgcn_s_barrier();                                                 \
+  if (!NO_BAR) __builtin_amdgcn_s_barrier();                                    \
   __builtin_amdgcn_sched_barrier(0);
   // The threshold filter of a finished tile runs in the L segments that FOLLOW its last MFMAs, not behind them in the
   // M segment: there this wave would hold the SIMD's matrix slot without using it (its partner is in its L segment,
@@ -742,15 +769,13 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st, hipEvent_t after_
   g = (g + 7) / 8 * 8;
 #ifdef HX_SCAN_DBG
   static const int dbg = getenv("HX_SCAN_DBG") ? atoi(getenv("HX_SCAN_DBG")) : 0;
-  if (kind == KIND_F16 && dbg == 1) hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 1>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_F16 && dbg == 2) hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 2>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_F16 && dbg == 3) hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 3>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_F16 && dbg == 4) hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 4>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_I8 && dbg == 1) hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 1>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_I8 && dbg == 2) hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 2>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_I8 && dbg == 3) hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 3>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else if (kind == KIND_I8 && dbg == 4) hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 4>), dim3((unsigned)g), dim3(512), 0, st, a);
-  else
+#define HX_DBG_CASE(K, D) \
+  if (kind == K && dbg == D) hipLaunchKernelGGL((k_scan8<K, HX_S8_TS, D>), dim3((unsigned)g), dim3(512), 0, st, a); else
+  HX_DBG_CASE(KIND_F16, 1) HX_DBG_CASE(KIND_F16, 2) HX_DBG_CASE(KIND_F16, 3) HX_DBG_CASE(KIND_F16, 4)
+  HX_DBG_CASE(KIND_I8, 1) HX_DBG_CASE(KIND_I8, 2) HX_DBG_CASE(KIND_I8, 3) HX_DBG_CASE(KIND_I8, 4)
+  HX_DBG_CASE(KIND_I8, 5) HX_DBG_CASE(KIND_I8, 6) HX_DBG_CASE(KIND_I8, 7) HX_DBG_CASE(KIND_I8, 8)
+  HX_DBG_CASE(KIND_I8, 9) HX_DBG_CASE(KIND_I8, 10)
+#undef HX_DBG_CASE
 #endif
   if (kind == KIND_F16)
     hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
