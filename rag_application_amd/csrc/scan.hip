@@ -33,6 +33,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+#ifndef HX_SCAN_NT
+#define HX_SCAN_NT 1
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -56,7 +60,17 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
   constexpr int LPW = A_LPW + B_LPW;
   static_assert(B_LPW >= 1, "BN >= 8 * waves");
 
+  // Per-query constants of the epilogue (threshold, int8 query scale) and the appends of this workgroup are kept in LDS:
+  // a VGPR-destination global load or a returning global atomic inside the stream is waited for with vmcnt, which
+  // counts in issue order -- the wait would drain the LDS-DMA ring ahead of it (round 3: the epilogue of every tile
+  // did, for the threshold; every append did, for its slot).
+  constexpr int TABQ = BN <= 128 ? BN : 512;        // queries the tables hold (nq_tiles * BN above that: global loads)
+  constexpr int LCAP = BN == 64 ? 512 : 1024;       // staged appends per workgroup (beyond: the global atomic, as before)
   __shared__ __attribute__((aligned(1024))) uint8_t lds[NSTAGE * STAGE];
+  __shared__ float lds_tau[TABQ], lds_rq[TABQ];
+  __shared__ uint64_t lds_key[LCAP];
+  __shared__ int lds_kq[LCAP];
+  __shared__ int lds_n;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,6 +107,14 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
   if (i0 >= items_x) return;
   const int my_items = (items_x - i0 + per_xcd - 1) / per_xcd;
   const int64_t total_steps = (int64_t)my_items * KT;
+  const bool tabs = nq * BN <= TABQ;
+  if (tabs)
+    for (int q = tid; q < nq * BN; q += BM * 2) {
+      lds_tau[q] = q < a.B ? g_tau[q] : __builtin_inff();
+      lds_rq[q] = (KIND == KIND_I8 && q < a.B) ? g_rinv_q[q] : 0.f;
+    }
+  if (tid == 0) lds_n = 0;
+  __syncthreads();
 
   // ---- load cursor -----------------------------------------------------------
   // Per tile, each lane keeps the byte offset of its 16-byte slot in every 1-KiB piece it
@@ -136,9 +158,16 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
     uint8_t* sbase = lds + st * STAGE;
     const int64_t koff = (int64_t)l_kt << 7;
 #pragma unroll
-    for (int c = 0; c < A_LPW; ++c)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(a_tile + a_off[c] + koff), LDS_PTR(sbase + (wave + NW * c) * 1024), 16,
-                                       0, 0);
+    for (int c = 0; c < A_LPW; ++c) {
+      // one query tile: every corpus row is read by exactly one workgroup, once -- non-temporal (aux = 2) keeps the
+      // stream from displacing the query tile in L2; with several query tiles the row tile is shared through L2
+      if (HX_SCAN_NT && nq == 1)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(a_tile + a_off[c] + koff), LDS_PTR(sbase + (wave + NW * c) * 1024),
+                                         16, 0, 2);
+      else
+        __builtin_amdgcn_global_load_lds(GLB_PTR(a_tile + a_off[c] + koff), LDS_PTR(sbase + (wave + NW * c) * 1024),
+                                         16, 0, 0);
+    }
 #pragma unroll
     for (int c = 0; c < B_LPW; ++c)
       __builtin_amdgcn_global_load_lds(GLB_PTR(q_tile + b_off[c] + koff),
@@ -215,17 +244,66 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
       c_kt = 0;
       const int rt = (int)(cj / nq) * 8 + xcd, qt = (int)(cj % nq);
       cj += per_xcd;
+      float rxm = 0.f;
+      if constexpr (KIND == KIND_I8) {
+        typedef __attribute__((address_space(4))) const float CF;   // uniform index: a scalar load
+        rxm = ((CF*)a.rinv_tile_max)[phys_row0(rt) >> 8];
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int q = qt * BN + wn * (TN * 32) + j * 32 + r;
         const bool qok = q < a.B;
-        const float tau = qok ? g_tau[q] : __builtin_inff();
-        float rq = 0.f;
-        if constexpr (KIND == KIND_I8) rq = qok ? g_rinv_q[q] : 0.f;
+        float tau, rq = 0.f;
+        if (tabs) {
+          tau = lds_tau[q];
+          rq = lds_rq[q];
+        } else {
+          tau = qok ? g_tau[q] : __builtin_inff();
+          if constexpr (KIND == KIND_I8) rq = qok ? g_rinv_q[q] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int64_t lrow0 = a.row_begin + (int64_t)rt * BM + wm * (TM * 32) + i * 32 + 4 * h;   // logical
           const int64_t row0 = phys_row0(rt) + wm * (TM * 32) + i * 32 + 4 * h;                    // physical
+          if constexpr (KIND == KIND_I8) {
+            // (f32(dot) * largest row scale of the 256-row tile) * query scale bounds the row's score from above
+            // (non-negative factors, monotone rounding; scan8.hip).  No per-row scale -- a VGPR-destination load -- is
+            // fetched in the stream: a row whose bound reaches the threshold is staged as (dot, row) and scored with its
+            // own scale when the workgroup has finished its tiles.
+            if (!a.all_pass) {
+              int im = acc[i][j][0];
+#pragma unroll
+              for (int e = 1; e < 16; ++e) im = acc[i][j][e] > im ? acc[i][j][e] : im;
+              const float bound = im > 0 ? ((float)im * rxm) * rq : 0.f;
+              if (__builtin_amdgcn_ballot_w64(bound >= tau) != 0ull) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+                  const int d = acc[i][j][e];
+                  const float be = d > 0 ? ((float)d * rxm) * rq : 0.f;
+                  if (be >= tau && row < a.n_total) {
+                    const int lp = __hip_atomic_fetch_add(&lds_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (lp < LCAP) {
+                      lds_key[lp] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)row;
+                      lds_kq[lp] = q;
+                    } else {             // staging area full: score and append at once
+                      const float sc1 = ((float)d * g_rinv_x[row]) * rq;
+                      if (sc1 >= tau) {
+                        const int pos = __hip_atomic_fetch_add(g_cnt + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (pos < a.cap)
+                          g_cand[(int64_t)q * a.cap + pos] = make_key(sc1, (uint32_t)(a.id_base + row));
+                        else
+                          g_ovf[q] = 1;
+                      }
+                    }
+                  }
+                }
+              }
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+              continue;
+            }
+          }
           float sc[16];
           if constexpr (KIND == KIND_F16) {
 #pragma unroll
@@ -254,11 +332,18 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
                   g_cand[(int64_t)q * a.cap + slot] =
                       (row < a.n_total && sc[e] >= tau) ? make_key(sc[e], (uint32_t)(a.id_base + row)) : 0ull;
               } else if (sc[e] >= tau && row < a.n_total) {
-                const int pos = __hip_atomic_fetch_add(g_cnt + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (pos < a.cap)
-                  g_cand[(int64_t)q * a.cap + pos] = make_key(sc[e], (uint32_t)(a.id_base + row));
-                else
-                  g_ovf[q] = 1;
+                const uint64_t key = make_key(sc[e], (uint32_t)(a.id_base + row));
+                const int lp = __hip_atomic_fetch_add(&lds_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lp < LCAP) {            // staged: placed when the workgroup has finished its tiles
+                  lds_key[lp] = key;
+                  lds_kq[lp] = q;
+                } else {
+                  const int pos = __hip_atomic_fetch_add(g_cnt + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (pos < a.cap)
+                    g_cand[(int64_t)q * a.cap + pos] = key;
+                  else
+                    g_ovf[q] = 1;
+                }
               }
             }
           }
@@ -267,6 +352,24 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
         }
       }
     }
+  }
+  // the staged appends of this workgroup
+  __syncthreads();
+  const int staged = lds_n < LCAP ? lds_n : LCAP;
+  for (int t = tid; t < staged; t += BM * 2) {
+    const int q = lds_kq[t];
+    if constexpr (KIND == KIND_I8) {      // (dot, row) -> the oracle's score, with the row's own scale
+      const int d = (int)(uint32_t)(lds_key[t] >> 32);
+      const uint32_t row = (uint32_t)lds_key[t];
+      const float sc1 = ((float)d * g_rinv_x[row]) * g_rinv_q[q];
+      if (!(sc1 >= g_tau[q])) continue;
+      lds_key[t] = make_key(sc1, (uint32_t)(a.id_base + row));
+    }
+    const int pos = __hip_atomic_fetch_add(g_cnt + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pos < a.cap)
+      g_cand[(int64_t)q * a.cap + pos] = lds_key[t];
+    else
+      g_ovf[q] = 1;
   }
 }
 
