@@ -109,6 +109,9 @@ __shared__ SpShared g_sp;
 #define S g_sp
 
 // LDS-only barrier: does not wait for outstanding global loads
+#ifndef HX_SP_HARVEST_BATCH
+#define HX_SP_HARVEST_BATCH 1
+#endif
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -406,6 +409,31 @@ __device__ __forceinline__ void sp_harvest(const uint4& p, uint32_t m, uint64_t*
   sp_append2(cand, a0 >= tau, a0, gbase + sp_doc(p.x), a1 >= tau, a1, gbase + sp_doc(p.z));   // tau >= 1: a cleared half never passes
 }
 
+// The 2 * SP_K takes of SP_K chunks, issued back to back and waited for ONCE (sp_harvest under a per-posting
+// predicate put `s_waitcnt lgkmcnt(0)` behind every take: six LDS round trips per wave and round).  A posting that
+// does not count ANDs, with all ones, the lane's own word of the accumulator -- 64 idle lanes on ONE word would
+// serialise (measured: 2.06 -> 3.40 ms) -- and its result is dropped.
+__device__ __forceinline__ void sp_harvest_batch(const uint4 (&p)[SP_K], const uint32_t (&m)[SP_K], int lane, uint64_t* cand,
+                                                 uint32_t tau, uint32_t gbase) {
+  uint32_t old[2 * SP_K];
+  uint32_t* const idle = S.acc + lane;
+#pragma unroll
+  for (int k = 0; k < SP_K; ++k) {
+    const uint32_t e0 = p[k].x, e1 = p[k].z;
+    old[2 * k] = __hip_atomic_fetch_and((m[k] & 1u) ? sp_word(e0) : idle, (m[k] & 1u) ? ~(0xFFFFu << (e0 >> 24)) : ~0u,
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old[2 * k + 1] = __hip_atomic_fetch_and((m[k] & 2u) ? sp_word(e1) : idle, (m[k] & 2u) ? ~(0xFFFFu << (e1 >> 24)) : ~0u,
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+#pragma unroll
+  for (int k = 0; k < SP_K; ++k) {
+    const uint32_t e0 = p[k].x, e1 = p[k].z;
+    const uint32_t a0 = (m[k] & 1u) ? (old[2 * k] >> (e0 >> 24)) & 0xFFFFu : 0u;
+    const uint32_t a1 = (m[k] & 2u) ? (old[2 * k + 1] >> (e1 >> 24)) & 0xFFFFu : 0u;
+    sp_append2(cand, a0 >= tau, a0, gbase + sp_doc(e0), a1 >= tau, a1, gbase + sp_doc(e1));   // tau >= 1: a cleared half never passes
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------
@@ -562,8 +590,17 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
       SP_STAMP(2)
       lds_barrier();                                    // ---- X: every posting of the segment is in
       SP_STAMP(3)
+#if HX_SP_HARVEST_BATCH
+      {
+        uint32_t hm[SP_K];
+#pragma unroll
+        for (int k = 0; k < SP_K; ++k) hm[k] = (mask >> (2 * k)) & 3u;
+        sp_harvest_batch(cur.p, hm, lane, cand, tau, gbase);
+      }
+#else
 #pragma unroll
       for (int k = 0; k < SP_K; ++k) sp_harvest(cur.p[k], (mask >> (2 * k)) & 3u, cand, tau, gbase, (tpack >> (24 + k)) & 1u);
+#endif
       for (uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave); c0 < nch; c0 += SP_K * SP_WAVES) {
         uint4 r[SP_K];
         uint32_t rm[SP_K];
@@ -580,8 +617,12 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
             r[k] = sp_load2(post, off, n, lane);
           }
         }
+#if HX_SP_HARVEST_BATCH
+        sp_harvest_batch(r, rm, lane, cand, tau, gbase);
+#else
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) sp_harvest(r[k], rm[k], cand, tau, gbase, false);
+#endif
       }
       SP_STAMP(4)
       lds_barrier();                                    // ---- Y: acc is all zero again
