@@ -552,23 +552,14 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
       const uint32_t mask = cur.mask;
       const uint32_t gbase = (uint32_t)(a.ix.id_base + (int64_t)seg * SEG_DOCS);
       const uint32_t tau = tau_r;
-#pragma unroll
-      for (int k = 0; k < SP_K; ++k)
-        sp_accumulate(cur.p[k], (mask >> (2 * k)) & 3u, sp_lane_f(qs_lane, (int)((tpack >> (6 * k)) & 63u)),
-                      (tpack >> (24 + k)) & 1u);
       // a dense segment: the chunks beyond the prefetched ones, SP_K at a time (their loads issued together); the
-      // directory is derived again from the table (a stage does not keep it: registers)
+      // directory is derived again from the table (a stage does not keep it: registers).  The loads of the first such
+      // round are issued BEFORE the prefetched slots are accumulated: their latency (HBM) runs under those adds.
       SpDir d{};
-      if (nch > (uint32_t)(SP_K * SP_WAVES)) {          // scalar: more chunks than the prefetched slots
-        asm volatile("" ::: "memory");                  // (keeps hipcc from hoisting this onto the common path)
-        uint32_t n2, olo, ohi;
-        offs(seg, olo, ohi);
-        d = sp_dir(olo, ohi, active, n2);
-      }
-      for (uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave); c0 < nch; c0 += SP_K * SP_WAVES) {
-        uint4 r[SP_K];
-        uint32_t rm[SP_K];
-        float rq[SP_K];
+      uint4 r[SP_K];
+      uint32_t rm[SP_K];
+      float rq[SP_K];
+      auto load_round = [&](uint32_t c0) {
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) {
           const uint32_t c = c0 + (uint32_t)(k * SP_WAVES);
@@ -584,23 +575,64 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
             r[k] = sp_load2(post, off, n, lane);
           }
         }
+      };
+      uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave);
+      if (nch > (uint32_t)(SP_K * SP_WAVES)) {          // scalar: more chunks than the prefetched slots
+        asm volatile("" ::: "memory");                  // (keeps hipcc from hoisting this onto the common path)
+        uint32_t n2, olo, ohi;
+        offs(seg, olo, ohi);
+        d = sp_dir(olo, ohi, active, n2);
+        if (c0 < nch) load_round(c0);
+      }
+#pragma unroll
+      for (int k = 0; k < SP_K; ++k)
+        sp_accumulate(cur.p[k], (mask >> (2 * k)) & 3u, sp_lane_f(qs_lane, (int)((tpack >> (6 * k)) & 63u)),
+                      (tpack >> (24 + k)) & 1u);
+      while (c0 < nch) {
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) sp_accumulate(r[k], rm[k], rq[k], false);
+        c0 += SP_K * SP_WAVES;
+        if (c0 < nch) load_round(c0);
       }
       SP_STAMP(2)
       lds_barrier();                                    // ---- X: every posting of the segment is in
       SP_STAMP(3)
 #if HX_SP_HARVEST_BATCH
       {
+        // chunks beyond the prefetched slots (a dense segment): the postings of the first such round are re-loaded
+        // (L2) BEFORE the takes of the prefetched slots, so their latency runs under those
+        uint4 r[SP_K];
+        uint32_t rm[SP_K];
+        auto load_round = [&](uint32_t c0) {
+#pragma unroll
+          for (int k = 0; k < SP_K; ++k) {
+            const uint32_t c = c0 + (uint32_t)(k * SP_WAVES);
+            rm[k] = 0;
+            r[k] = make_uint4(0, 0, 0, 0);
+            if (c < nch) {
+              uint32_t off, n;
+              int t;
+              sp_chunk(d, c, off, n, t);
+              rm[k] = sp_lanebits(n, lane);
+              r[k] = sp_load2(post, off, n, lane);
+            }
+          }
+        };
+        uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave);
+        if (c0 < nch) load_round(c0);
         uint32_t hm[SP_K];
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) hm[k] = (mask >> (2 * k)) & 3u;
         sp_harvest_batch(cur.p, hm, lane, cand, tau, gbase);
+        while (c0 < nch) {
+          sp_harvest_batch(r, rm, lane, cand, tau, gbase);
+          c0 += SP_K * SP_WAVES;
+          if (c0 < nch) load_round(c0);
+        }
       }
 #else
 #pragma unroll
       for (int k = 0; k < SP_K; ++k) sp_harvest(cur.p[k], (mask >> (2 * k)) & 3u, cand, tau, gbase, (tpack >> (24 + k)) & 1u);
-#endif
       for (uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave); c0 < nch; c0 += SP_K * SP_WAVES) {
         uint4 r[SP_K];
         uint32_t rm[SP_K];
@@ -617,13 +649,10 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
             r[k] = sp_load2(post, off, n, lane);
           }
         }
-#if HX_SP_HARVEST_BATCH
-        sp_harvest_batch(r, rm, lane, cand, tau, gbase);
-#else
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) sp_harvest(r[k], rm[k], cand, tau, gbase, false);
-#endif
       }
+#endif
       SP_STAMP(4)
       lds_barrier();                                    // ---- Y: acc is all zero again
       SP_STAMP(5)
