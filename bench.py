@@ -462,10 +462,22 @@ def main():
             return sh.hybrid_h1(q, ip, ixx, vv, 100, 100, 10)
         return sh.search_dense(q, 10)
 
-    for _ in range(args.warmup):
-        step()
-    if pipe is not None:
-        pipe.wait()
+    pipe_note = None
+    try:
+        for _ in range(args.warmup):
+            step()
+        if pipe is not None:
+            pipe.wait()
+    except Exception as e:      # noqa: BLE001
+        # N > 1 only: an error every rank sees alike in the pipelined exchange (it has run over gloo and over RCCL with one
+        # rank only) must not cost the line -- fall back to the synchronous exchange and say so
+        if pipe is None:
+            raise
+        pipe_note = repr(e)[:300]
+        pipe = None
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
     ix.profile(True)
     ix.profile_read()
     if world > 1:
@@ -618,6 +630,7 @@ def main():
                        "sharding": f"rows/{world}", "nnz_per_shard": st["nnz"],
                        # N > 1: the exchange + fusion of batch i overlap the local stage of batch i + 1
                        "batches_in_flight": 2 if pipe is not None else 1,
+                       **({"pipeline_fallback": pipe_note} if pipe_note else {}),
                        "exact_fallback_queries": st["dense_fallback_queries"], "retry_queries": st["retry_queries"],
                        "sparse_fallback_queries": st["sparse_fallback_queries"], "build_s": round(t_build, 2),
                        **({"sharded_equals_single_index": verified} if verified is not None else {})},
