@@ -914,6 +914,46 @@ def test_scan8_underflow_retry(eng, torch_mod, monkeypatch, order):
     ix.close()
 
 
+@pytest.mark.parametrize("B", [20, 40, 100])
+def test_small_batch_scan_staging_overflows(eng, torch_mod, monkeypatch, B):
+    """k_scan (batches below 256 queries) stages a workgroup's appends in LDS and places them when its tiles are done; rows
+    past the staging area go through the global counter at once, rows past a query's candidate buffer flag it.  Scanned in
+    physical order (HX_DEBUG_NO_PERM) with the rows most similar to the queries LAST, every later chunk passes far more
+    rows than its threshold was set for: staging area and candidate buffers overflow, the queries are retried -- and the
+    lists are the oracle's all the same (dense through both candidate kinds, the "quantized" int8 stage)."""
+    from oracle import c_oracle as CO
+    monkeypatch.setenv("HX_DEBUG_NO_PERM", "1")
+    n, dim, limit = 40000, 128, 50
+    rng = np.random.default_rng(11)
+    Q = O.synth_dense(72, 0, B, dim)
+    X = O.synth_dense(71, 0, n, dim)
+    w = np.sort(rng.uniform(0.0, 1.5, n)).astype(np.float32)[:, None]      # similarity to SOME query grows with the row index
+    X = (w * Q[rng.integers(0, B, n)] + X).astype(np.float32)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    es, ei, ec = _c_expected_dense(X, Q, limit)
+    for kind in ("f16", "i8"):
+        ix.set_dense_candidates(kind)
+        s, i, c = unpack_np(eng, *ix.search_dense(Qd, limit))
+        for b in range(B):
+            assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"staging {kind} b={b}")
+    st = ix.stats()
+    if B <= 40:       # (100 queries share the planted rows: fewer per query, the buffers hold)
+        assert st["retry_queries"] > 0, "no buffer overflowed: the test does not exercise what it is for"
+    ix.close()
+    Xu, Qu = CO.cosine_preprocess(X), CO.cosine_preprocess(Q)
+    ix8 = eng.HxIndex(dim, ())
+    ix8.add(Xu)
+    X8, rx = CO.quantize_i8(Xu)
+    Q8, rq = CO.quantize_i8(Qu)
+    es, ei, ec = CO.search_i8(X8, rx, Q8, rq, limit)
+    s, i, c = unpack_np(eng, *ix8.search_i8(torch_mod.from_numpy(Qu).cuda(), limit))
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"staging quantized b={b}")
+    ix8.close()
+
+
 def test_clustered_row_order_stays_on_the_fast_path(eng, torch_mod):
     """A corpus ingested document by document is topically clustered: the rows most similar to a query sit
     together.  With the scan's strided tile order (kernels.hpp) every chunk samples the whole matrix, so clusters of
