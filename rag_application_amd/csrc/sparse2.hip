@@ -109,6 +109,9 @@ __shared__ SpShared g_sp;
 #define S g_sp
 
 // LDS-only barrier: does not wait for outstanding global loads
+#ifndef HX_SP_ACC_BRANCHFREE
+#define HX_SP_ACC_BRANCHFREE 0   // 1: measured 1.96-1.97 ms against 1.905-1.91 (the idle adds cost more than the branches)
+#endif
 #ifndef HX_SP_HARVEST_BATCH
 #define HX_SP_HARVEST_BATCH 1
 #endif
@@ -379,8 +382,17 @@ __device__ __forceinline__ void sp_accumulate(const uint4& p, uint32_t m, float 
     sp_add1(p.x, sp_units(p.y, qs));
     sp_add1(p.z, sp_units(p.w, qs));
   } else {
+#if HX_SP_ACC_BRANCHFREE
+    // no per-posting predicate (two exec-mask branches per slot): a posting that does not count adds 0 to the lane's own word
+    uint32_t* const idle = S.acc + (threadIdx.x & 63);
+    __hip_atomic_fetch_add((m & 1u) ? sp_word(p.x) : idle, (m & 1u) ? sp_units(p.y, qs) << (p.x >> 24) : 0u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add((m & 2u) ? sp_word(p.z) : idle, (m & 2u) ? sp_units(p.w, qs) << (p.z >> 24) : 0u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     if (m & 1u) sp_add1(p.x, sp_units(p.y, qs));
     if (m & 2u) sp_add1(p.z, sp_units(p.w, qs));
+#endif
   }
 }
 __device__ __forceinline__ uint32_t sp_take1(uint32_t e) {
