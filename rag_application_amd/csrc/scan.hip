@@ -20,6 +20,7 @@
 // 128 B) into an NSTAGE ring; the LDS image is lane-linear, the 16-B slot XOR
 // swizzle ((row>>1)&7) is applied on the SOURCE address and again on the
 // ds_read_b128 address, so every 16-lane read group hits 16 distinct bank slots.
+#include <stdlib.h>
 #include "hx_common.hpp"
 #include "kernels.hpp"
 
@@ -45,7 +46,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Tile shapes: 256 x 256 with 8 waves (each 128 x 64: 4 x 2 MFMA tiles, 0.75 LDS fragment
 // reads per MFMA, 128 KiB of LDS, one workgroup per CU) for large batches; 128 x {128,64,32}
 // with 4 waves (two workgroups per CU) for small ones.
-template <int KIND, int BM, int BN, int NSTAGE>
+// QRES (one query tile whose rows are at most QRES_KT * 128 bytes): the query tile is loaded ONCE into its own LDS area
+// and stays there; the ring carries corpus rows only -- a fifth fewer LDS-DMA pieces per k-step at 32 queries.
+constexpr int QRES_KT = 6;
+template <int KIND, int BM, int BN, int NSTAGE, bool QRES = false>
 __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
   constexpr int NW = BM / 32;                       // waves: 8 or 4
   constexpr int WN = BN >= 256 ? 4 : (BN >= 64 ? 2 : 1);
@@ -54,10 +58,10 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
   constexpr int TN = BN / WN / 32;
   constexpr int A_BYTES = BM * 128;
   constexpr int B_BYTES = BN * 128;
-  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int STAGE = A_BYTES + (QRES ? 0 : B_BYTES);
   constexpr int A_LPW = BM / 8 / NW;  // 1-KiB pieces per wave
   constexpr int B_LPW = BN / 8 / NW;
-  constexpr int LPW = A_LPW + B_LPW;
+  constexpr int LPW = A_LPW + (QRES ? 0 : B_LPW);
   static_assert(B_LPW >= 1, "BN >= 8 * waves");
 
   // Per-query constants of the epilogue (threshold, int8 query scale) and the appends of this workgroup are kept in LDS:
@@ -65,8 +69,9 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
   // counts in issue order -- the wait would drain the LDS-DMA ring ahead of it (round 3: the epilogue of every tile
   // did, for the threshold; every append did, for its slot).
   constexpr int TABQ = BN <= 128 ? BN : 512;        // queries the tables hold (nq_tiles * BN above that: global loads)
-  constexpr int LCAP = BN == 64 ? 512 : 1024;       // staged appends per workgroup (beyond: the global atomic, as before)
-  __shared__ __attribute__((aligned(1024))) uint8_t lds[NSTAGE * STAGE];
+  constexpr int LCAP = (BN == 64 || QRES) ? 512 : 1024;   // staged appends per workgroup (beyond: the global atomic, as before)
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[NSTAGE * STAGE + (QRES ? QRES_KT * B_BYTES : 0)];
+  uint8_t* const qres = lds + NSTAGE * STAGE;
   __shared__ float lds_tau[TABQ], lds_rq[TABQ];
   __shared__ uint64_t lds_key[LCAP];
   __shared__ int lds_kq[LCAP];
@@ -168,10 +173,12 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
         __builtin_amdgcn_global_load_lds(GLB_PTR(a_tile + a_off[c] + koff), LDS_PTR(sbase + (wave + NW * c) * 1024),
                                          16, 0, 0);
     }
+    if constexpr (!QRES) {
 #pragma unroll
-    for (int c = 0; c < B_LPW; ++c)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(q_tile + b_off[c] + koff),
-                                       LDS_PTR(sbase + A_BYTES + (wave + NW * c) * 1024), 16, 0, 0);
+      for (int c = 0; c < B_LPW; ++c)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(q_tile + b_off[c] + koff),
+                                         LDS_PTR(sbase + A_BYTES + (wave + NW * c) * 1024), 16, 0, 0);
+    }
     ++l_step;
     if (++l_kt == KT) {
       l_kt = 0;
@@ -190,6 +197,15 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
+  if constexpr (QRES) {     // the whole query tile, once (launch_scan: nq_tiles == 1, KT <= QRES_KT)
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int c = 0; c < B_LPW; ++c)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(q_tile + b_off[c] + ((int64_t)kt << 7)),
+                                         LDS_PTR(qres + kt * B_BYTES + (wave + NW * c) * 1024), 16, 0, 0);
+    }
+    wait_vmcnt<0>();        // this wave's pieces; the other waves' are behind the first barrier of the loop
+  }
   // prologue: NSTAGE-1 steps in flight
 #pragma unroll
   for (int p = 0; p < NSTAGE - 1; ++p)
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
     if (l_step < total_steps) issue_load();  // into the stage compute(s-1) just released
 
     const uint8_t* As = lds + (int)(s % NSTAGE) * STAGE;
-    const uint8_t* Bs = As + A_BYTES;
+    const uint8_t* Bs = QRES ? qres + c_kt * B_BYTES : As + A_BYTES;
     // all fragments of the k-step first (16-byte LDS reads, conflict free), then the MFMAs:
     // hipcc interleaves them behind counted lgkmcnt waits
     half8 af[4][TM], bf[4][TN];
@@ -373,12 +389,12 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
   }
 }
 
-template <int KIND, int BM, int BN, int NSTAGE>
+template <int KIND, int BM, int BN, int NSTAGE, bool QRES = false>
 static void launch(const ScanArgs& a, int64_t tiles, hipStream_t st) {
   constexpr int per_cu = BM == 256 ? 1 : 2;
   int64_t g = tiles < 256 * per_cu ? tiles : 256 * per_cu;
   g = (g + 7) / 8 * 8;  // whole XCD groups; blocks without items exit at once
-  hipLaunchKernelGGL((k_scan<KIND, BM, BN, NSTAGE>), dim3((unsigned)g), dim3(BM * 2), 0, st, a);
+  hipLaunchKernelGGL((k_scan<KIND, BM, BN, NSTAGE, QRES>), dim3((unsigned)g), dim3(BM * 2), 0, st, a);
 }
 
 void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st, hipEvent_t after_kernel) {
@@ -388,15 +404,19 @@ void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st, hipEvent_t
   if (scan8_usable(a, bn)) return launch_scan8(a, kind, st, after_kernel);
   const int bm = bn == 256 ? 256 : 128;
   const int64_t tiles = (n_rows + bm - 1) / bm * a.nq_tiles;
+  static const bool qres_on = !getenv("HX_DEBUG_NO_QRES");      // diagnostics: the streamed query tile for every shape
+  const bool qres = qres_on && bn == 32 && a.nq_tiles == 1 && a.row_bytes <= QRES_KT * 128;
   if (kind == KIND_F16) {
     if (bn == 256) launch<KIND_F16, 256, 256, 2>(a, tiles, st);
     else if (bn == 128) launch<KIND_F16, 128, 128, 2>(a, tiles, st);
     else if (bn == 64) launch<KIND_F16, 128, 64, 3>(a, tiles, st);
+    else if (qres) launch<KIND_F16, 128, 32, 3, true>(a, tiles, st);
     else launch<KIND_F16, 128, 32, 3>(a, tiles, st);
   } else {
     if (bn == 256) launch<KIND_I8, 256, 256, 2>(a, tiles, st);
     else if (bn == 128) launch<KIND_I8, 128, 128, 2>(a, tiles, st);
     else if (bn == 64) launch<KIND_I8, 128, 64, 3>(a, tiles, st);
+    else if (qres) launch<KIND_I8, 128, 32, 3, true>(a, tiles, st);
     else launch<KIND_I8, 128, 32, 3>(a, tiles, st);
   }
   HX_HIP(hipGetLastError());
