@@ -93,6 +93,28 @@ def test_derived_rows_bit_exact(eng, torch_mod, synth_tables):
     ix.close()
 
 
+def test_fp32_division_is_correctly_rounded(eng, torch_mod):
+    """K1 divides every element by its row's length (prep.hip: through fp64, innocuous double rounding; hipcc's fp32 IEEE
+    sequence passes this test too and is no faster -- the kernel is not bound by its vector instructions).  4096 rows x 1024
+    elements spread over sixty binades -- row scales 2^-40 .. 2^20, elements down to 2^-40 of their row's largest, zeros,
+    quotients in the denormal range -- must equal numpy's float32 quotients bit for bit."""
+    n, dim = 4096, 1024
+    rng = np.random.default_rng(123)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    X *= np.exp2(-rng.uniform(0, 40, (n, dim))).astype(np.float32)
+    X[rng.random((n, dim)) < 0.01] = 0.0
+    X = (X * np.exp2(rng.uniform(-40, 20, n)).astype(np.float32)[:, None]).astype(np.float32)
+    X[:64] *= np.float32(2.0 ** -60)                    # tiny rows: quotients of denormal operands
+    exp = O.cosine_preprocess(X)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    bad = 0
+    for r in range(n):
+        bad += int(np.count_nonzero(ix.debug_row(0, r).view(np.uint32) != exp[r].view(np.uint32)))
+    ix.close()
+    assert bad == 0, f"{bad} of {n * dim} stored elements differ from numpy's quotient"
+
+
 @pytest.mark.parametrize("B,limit,prefix", [(1, 10, 0), (7, 10, 0), (40, 100, 0), (130, 10, 0), (33, 500, 64),
                                             (5, 100, 64), (3, 60, 128), (3, 40, 256)])
 def test_search_dense(small, eng, torch_mod, B, limit, prefix):
