@@ -85,9 +85,10 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   // 7 as 6 without the barriers, 8 no loads and no filter, 9 / 10 below
   constexpr bool NO_READS = DBG == 5 || DBG == 6 || DBG == 7;
   constexpr bool NO_GLDS = DBG == 2 || DBG == 6 || DBG == 7 || DBG == 8;
-  constexpr bool NO_FILTER = DBG == 4 || DBG == 6 || DBG == 7 || DBG == 8 || DBG == 9 || DBG == 10;
+  constexpr bool NO_FILTER = DBG == 4 || DBG == 6 || DBG == 7 || DBG == 8 || DBG == 9 || DBG == 10 || DBG == 11;
   constexpr bool NO_VMWAIT = DBG == 9;     // 9: no filter and no counted waits (the loads are issued, nothing waits for them)
   constexpr bool ONE_TILE = DBG == 1 || DBG == 10;   // 10: 1 without the filter
+  constexpr bool L2_TILES = DBG == 11;               // 11: no filter, every XCD alternates between TWO row tiles: rows from L2, not from L1
   constexpr bool NO_BAR = DBG == 7;
   __shared__ __attribute__((aligned(1024))) uint8_t lds[8 * S8_HT + AUX];
   float* lds_tau = (float*)(lds + 8 * S8_HT);
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   };
   auto tile_ptrs = [&](int j, Cur& c) __attribute__((always_inline)) {
     const int d = __builtin_amdgcn_readfirstlane(j / nq);   // keep the cursor in scalar registers
-    const int rt = ONE_TILE ? 0 : d * 8 + xcd, qt = j - d * nq;
+    const int rt = ONE_TILE ? 0 : (L2_TILES ? (d & 1) * 8 + xcd : d * 8 + xcd), qt = j - d * nq;
     c.a = a.A + (int64_t)phys_tile(rt) * 256 * a.row_bytes;
     c.q = a.Q + (int64_t)qt * 256 * a.row_bytes;
   };
@@ -774,7 +775,7 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st, hipEvent_t after_
   HX_DBG_CASE(KIND_F16, 1) HX_DBG_CASE(KIND_F16, 2) HX_DBG_CASE(KIND_F16, 3) HX_DBG_CASE(KIND_F16, 4)
   HX_DBG_CASE(KIND_I8, 1) HX_DBG_CASE(KIND_I8, 2) HX_DBG_CASE(KIND_I8, 3) HX_DBG_CASE(KIND_I8, 4)
   HX_DBG_CASE(KIND_I8, 5) HX_DBG_CASE(KIND_I8, 6) HX_DBG_CASE(KIND_I8, 7) HX_DBG_CASE(KIND_I8, 8)
-  HX_DBG_CASE(KIND_I8, 9) HX_DBG_CASE(KIND_I8, 10)
+  HX_DBG_CASE(KIND_I8, 9) HX_DBG_CASE(KIND_I8, 10) HX_DBG_CASE(KIND_I8, 11)
 #undef HX_DBG_CASE
 #endif
   if (kind == KIND_F16)
