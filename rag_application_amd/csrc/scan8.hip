@@ -660,7 +660,12 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 // column group (wave & 3), i.e. at most 64 * nq_tiles distinct queries: pass 1 counts per query in
 // LDS, ONE global atomic per (workgroup, query) reserves a range, pass 2 re-reads the logs and
 // places the keys with LDS atomics.
-constexpr int S8_SB = 8;
+#ifndef HX_S8_WPL
+#define HX_S8_WPL 2     // waves of the scatter workgroup per log (the walk is a chain of dependent loads per entry: more waves
+#endif                  // per log shorten it, at the price of more workgroups and one global atomic per workgroup and query;
+                        // everything of a dense search but its scan kernels, B = 1024, L = 100: 0.857 / 0.75 / 0.747 ms at 1 / 2 / 4)
+constexpr int S8_WPL = HX_S8_WPL;
+constexpr int S8_SB = 8 / S8_WPL;
 template <int KIND, int TS>
 __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __restrict__ hitcnt,
                                                       int logcap, int n_scan_blocks, int nq_tiles,
@@ -677,8 +682,9 @@ __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __r
   const int nloc = nq_tiles * 64;                     // queries of the group: q = qt*256 + wn*64 + j
   for (int i = tid; i < nloc; i += 1024) lcnt[i] = 0;
   __syncthreads();
-  static_assert(2 * S8_SB == 1024 / 64, "one wave of the workgroup per log");
-  const int l = tid >> 6, lane = tid & 63;            // wave l walks log l: the 16 logs advance together
+  static_assert(2 * S8_SB * S8_WPL == 1024 / 64, "S8_WPL waves of the workgroup per log");
+  const int l = (tid >> 6) / S8_WPL, lane = tid & 63; // waves l * S8_WPL ... walk log l: the logs advance together
+  const int sub = (tid >> 6) % S8_WPL;
   const int sb = sb0 + (l >> 1);
   const int w = sb * 8 + (l & 1) * 4 + wn;            // waves wn and wn + 4 of the scan workgroup
   int n = sb < n_scan_blocks ? hitcnt[w] : 0;
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __r
   // not four gathers), counts the passing ones with ONE LDS atomic per entry and leaves their bit mask in the
   // entry's spare header word; pass 1 -- after the workgroup reserved a range per query -- touches only entries with a
   // mask and only their passing elements (about one of sixteen), with one LDS atomic per entry again.
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane + 64 * sub; i < n; i += 64 * S8_WPL) {
     uint4* e = base + (int64_t)i * ENTRY;
     const uint4 h = e[0];
     const int q = (int)h.x;
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __r
     lcnt[i] = c > 0 ? atomicAdd(cnt + q, c) : 0;   // first slot of this workgroup's range
   }
   __syncthreads();
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane + 64 * sub; i < n; i += 64 * S8_WPL) {
     const uint4* e = base + (int64_t)i * ENTRY;
     const uint4 h = e[0];                          // (its mask word was written by this very lane above)
     uint32_t mask = h.w;
