@@ -1549,3 +1549,35 @@ def test_int8_candidate_bound_holds_pair_by_pair(eng, torch_mod):
         spec = np.array([O.spec_dot(Xn[r:r + 1].astype(np.float32), q.astype(np.float32))[0] for r in range(n)], np.float64)
         assert (np.abs(spec - s8) <= eps).all(), (b, float(np.abs(spec - s8).max()), eps)
     ix.close()
+
+
+def test_cfg4_shard_shape_full_size(eng, torch_mod):
+    """BASELINE config 4 (100M x 768 over 8 GPUs) is 12.5M rows + 1.25e9 postings per GPU: that shard, whole (112 GB of HBM),
+    through the one-call hybrid query at B = 1024, and eight of its queries brute-forced on the host over all 12.5M rows
+    (the C restatement, corpus regenerated chunk by chunk: `bench.cpu_baseline`, the gate of the bench's own timed step) --
+    ids and fp32 score bits of dense top-100 (+) sparse top-100 -> RRF -> top-10."""
+    import os
+    import bench
+    from rag_application_amd import synth
+    rows, dim, B = 12_500_000, 768, 1024
+    tabs = synth.tables()
+    ix = eng.HxIndex(dim, (64, 128, 256))
+    try:
+        ix.reserve(rows)
+        ix.synth_fill(rows, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs)
+        ix.finalize()
+        Q = eng.synth_queries_dense(dim, 0, B, synth.SEED_QUERY)
+        qip, qix, qv = (torch_mod.from_numpy(a).cuda() for a in synth.sparse_queries(synth.SEED_SPQUERY, 0, B, tabs))
+        hp = eng.make_params(dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=60, dense_limit=100,
+                                  quantized_limit=40, sparse_limit=100, final_limit=10, hnsw_ef=128), mode=eng.HX_MODE_H1)
+        keys, cnt = ix.hybrid_query(Q, qip, qix, qv, hp)
+        st = ix.stats()
+        s, i, c = unpack_np(eng, keys, cnt)
+    finally:
+        ix.close()
+    sel = np.arange(0, B, 128)
+    out = bench.cpu_baseline(dict(rows=rows, mode="h1", batch=B), sel, dim, tabs, (s, i, c),
+                             threads=min(16, os.cpu_count() or 1))
+    assert out["parity_on_sample"], "a list of the 12.5M-row shard differs from the host brute force"
+    assert out["recall_at_10"] == 1.0
+    assert st["dense_fallback_queries"] == 0 and st["sparse_fallback_queries"] == 0
