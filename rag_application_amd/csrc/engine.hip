@@ -530,7 +530,8 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false) {
       }
     }
     // (int8 candidates, L' = 450: growth 63 / 24 / 16 / 12 / 8 -> 2 / 3 / 3 / 4 / 4 launches per 10M rows, 10.69 /
-    // 10.53 / 10.48 / 10.47 / 10.48 ms per step: the appended volume per launch falls with the growth)
+    // 10.53 / 10.48 / 10.47 / 10.48 ms per step: the appended volume per launch falls with the growth; again with the
+    // cheaper log scatter of late round 3, dense search only: 50 / 24 / 16 / 12 -> 7.53 / 7.44 / 7.43 / 7.44 ms)
     static const int gmax8 = getenv("HX_DEBUG_GROW_MAX8") ? std::max(3, atoi(getenv("HX_DEBUG_GROW_MAX8"))) : 16;
     static const int gmax = getenv("HX_DEBUG_GROW_MAX") ? std::max(3, atoi(getenv("HX_DEBUG_GROW_MAX"))) : 64;
     for (int gr = std::min(64, cand8 ? gmax8 : gmax); gr > 2; --gr) {
