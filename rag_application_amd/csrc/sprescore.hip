@@ -177,8 +177,11 @@ void launch_sparse_plan(const unsigned long long* q_work, int B, int pt_max, int
 // ---------------------------------------------------------------------------------
 // exact score of (query, document) on one wave
 // ---------------------------------------------------------------------------------
+// PRE: the query's terms and weights are held by the wave (lane t: term t, T <= 64) instead of being loaded term by term
+template <bool PRE = false>
 __device__ __forceinline__ float sp_exact_score(const SparseCsr& d, int64_t doc, const int32_t* q_idx,
-                                                const float* q_val, int64_t qb, int T, int lane, bool& any) {
+                                                const float* q_val, int64_t qb, int T, int lane, bool& any,
+                                                int32_t qi_lane = 0, float qw_lane = 0.0f) {
   const int64_t b = d.indptr[doc], e = d.indptr[doc + 1];
   // the document's first 128 terms live in registers; longer documents re-read the rest per query term
   const int32_t i0 = b + lane < e ? d.idx[b + lane] : -1;
@@ -189,7 +192,7 @@ __device__ __forceinline__ float sp_exact_score(const SparseCsr& d, int64_t doc,
   float acc = 0.0f;
   any = false;
   for (int t = 0; t < T; ++t) {
-    const int32_t term = q_idx[qb + t];
+    const int32_t term = PRE ? __builtin_amdgcn_readlane(qi_lane, t) : q_idx[qb + t];
     bool hit = false;
     float w = 0.0f;
     unsigned long long m = __ballot(i0 == term);
@@ -212,7 +215,8 @@ __device__ __forceinline__ float sp_exact_score(const SparseCsr& d, int64_t doc,
         }
     }
     if (hit) {                                       // wave-uniform
-      acc = __fadd_rn(acc, __fmul_rn(q_val[qb + t], w));
+      const float qw = PRE ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qw_lane), t)) : q_val[qb + t];
+      acc = __fadd_rn(acc, __fmul_rn(qw, w));
       any = true;
     }
   }
@@ -251,6 +255,10 @@ __global__ __launch_bounds__(256) void k_sparse_rescore(SparseRescoreArgs a) {
   }
   const int64_t qb = a.q_indptr[b];
   const int T = (int)(a.q_indptr[b + 1] - qb);
+  // the query's terms once per wave (one vector load each) instead of one dependent scalar load per term and candidate
+  const bool pre = T <= 64;
+  const int32_t qi_lane = (pre && lane < T) ? a.q_idx[qb + lane] : -1;
+  const float qw_lane = (pre && lane < T) ? a.q_val[qb + lane] : 0.0f;
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += SPR_BLOCKS * 4) {   // wave-uniform
     const uint64_t ck = list[i];
     if ((uint32_t)(ck >> 32) < thr) break;      // sorted: nothing further passes
@@ -258,7 +266,8 @@ __global__ __launch_bounds__(256) void k_sparse_rescore(SparseRescoreArgs a) {
     const int64_t doc = (int64_t)(0xFFFFFFFFu - (uint32_t)ck) - a.d.id_base;
     if (doc >= 0 && doc < a.d.n_docs) {
       bool any;
-      const float s = sp_exact_score(a.d, doc, a.q_idx, a.q_val, qb, T, lane, any);
+      const float s = pre ? sp_exact_score<true>(a.d, doc, a.q_idx, a.q_val, qb, T, lane, any, qi_lane, qw_lane)
+                          : sp_exact_score<false>(a.d, doc, a.q_idx, a.q_val, qb, T, lane, any);
       if (any) k = make_key(s, (uint32_t)(a.d.id_base + doc));
     }
     if (lane == 0) out[i] = k;
