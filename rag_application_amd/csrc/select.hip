@@ -389,6 +389,44 @@ __global__ __launch_bounds__(256) void k_rrf(const uint64_t* a, int a_stride, co
   const uint64_t* la = a + (int64_t)q * a_stride;
   const uint64_t* lb = b + (int64_t)q * b_stride;
   uint64_t* o = out + (int64_t)q * (a_stride + b_stride);
+  // Lists of up to RRF_LDS entries: the ids of both go to LDS first (coalesced loads); a thread's search of the OTHER list
+  // was a chain of dependent global loads, one per entry until the match (29 us per 1024-query batch of two 100-entry lists).
+  constexpr int RRF_LDS = 1024;
+  __shared__ uint32_t ida[RRF_LDS], idb[RRF_LDS];
+  if (na <= RRF_LDS && nb <= RRF_LDS) {
+    for (int i = tid; i < na; i += 256) ida[i] = key_id(la[i]);
+    for (int j = tid; j < nb; j += 256) idb[j] = key_id(lb[j]);
+    __syncthreads();
+    for (int i = tid; i < a_stride; i += 256) {
+      uint64_t r = 0ull;
+      if (i < na) {
+        const uint32_t id = ida[i];
+        float s = __fadd_rn(0.0f, rcp_f32_rn(__fadd_rn((float)(i + rank_base), k)));
+        for (int j = 0; j < nb; ++j)
+          if (idb[j] == id) {
+            s = __fadd_rn(s, rcp_f32_rn(__fadd_rn((float)(j + rank_base), k)));
+            break;
+          }
+        r = make_key(s, id);
+      }
+      o[i] = r;
+    }
+    for (int j = tid; j < b_stride; j += 256) {
+      uint64_t r = 0ull;
+      if (j < nb) {
+        const uint32_t id = idb[j];
+        bool dup = false;
+        for (int i = 0; i < na; ++i)
+          if (ida[i] == id) {
+            dup = true;
+            break;
+          }
+        if (!dup) r = make_key(__fadd_rn(0.0f, rcp_f32_rn(__fadd_rn((float)(j + rank_base), k))), id);
+      }
+      o[a_stride + j] = r;
+    }
+    return;
+  }
   for (int i = tid; i < a_stride; i += 256) {
     uint64_t r = 0ull;
     if (i < na) {
