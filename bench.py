@@ -70,6 +70,9 @@ def _merge_best(best, s, i, c, L):
     return out
 
 
+HOST_SHARE = {}
+
+
 def host_share():
     """(threads, note): the host cores that belong to one GPU of this box = cores the process may run on, divided by
     the GPUs of the host (KFD topology: every GPU of the machine is listed there even when one is handed to us)."""
@@ -91,9 +94,12 @@ def host_share():
         gpus = max(gpus, torch.cuda.device_count())
     except Exception:
         pass
+    visible = gpus
     if cores >= 128:
         gpus = max(gpus, 8)
     gpus = max(gpus, 1)
+    HOST_SHARE.update(usable_host_cores=cores, visible_gpus=visible, assumed_gpus_of_host=gpus,
+                      rule="cores // max(visible GPUs, 8 if cores >= 128 else 1): a reported baseline, no speed-up claim rests on it")
     return max(1, cores // gpus), f"{cores} usable host cores / {gpus} GPUs of the host (an MI355X node carries 8)"
 
 
@@ -170,6 +176,7 @@ def cpu_baseline(wl, sel, dim, tabs, res_keys, chunk_rows=1_000_000, share_note=
                        f"brute force chunk by chunk ({t_cpu:.2f} s of CPU search work, data generation not counted); "
                        f"document-at-a-time sparse scoring; every chunk's search timed three times, the medians summed; "
                        f"{threads} threads = {share_note}",
+                host_share=dict(HOST_SHARE),
                 parity_on_sample=bool(ok), recall_at_10=(hit / want if want else None),
                 checked="ids and fp32 score bits of the LAST TIMED STEP's lists for the sampled queries")
 
@@ -215,6 +222,29 @@ def ingest_leg(eng, synth, torch, local, t_build, rows, nnz, tabs):
             sc.close()
             del Xd
         del X
+        # K1/K2 in steady state: 1M rows already on the device = 16 launches of k_prep_rows (65536 rows each); the two
+        # legs above time two cold launches each, which is what an upsert of 131072 chunks costs, not what the kernel does
+        n_st = 1 << 20
+        sc = eng.HxIndex(dim, (64, 128, 256), device=local)
+        sc.reserve(n_st)
+        Xd = torch.rand((n_st, dim), device=f"cuda:{local}", dtype=torch.float32) * 2.0 - 1.0
+        sc.add_device(Xd[:65536].contiguous())          # first-touch of the buffers
+        sc.truncate(0)
+        sc.profile(True)
+        sc.profile_read()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sc.add_device(Xd)
+        torch.cuda.synchronize()
+        t_add = time.perf_counter() - t0
+        pr = sc.profile_read()["prep_rows"]
+        out["prep_rows_steady"] = dict(rows=n_st, chunks_per_sec=n_st / t_add, launches=pr["launches"], ms=pr["ms"],
+                                       alg_gb=pr["bytes"] / 1e9, gbs=pr["bytes"] / pr["ms"] / 1e6 if pr["ms"] else None,
+                                       frac_of_hbm_peak=pr["bytes"] / pr["ms"] / 1e6 / PEAK_HBM_GBS if pr["ms"] else None,
+                                       note="K1/K2 (k_prep_rows) over 16 consecutive launches, HIP events per launch: D*4 read + "
+                                            "every derived copy written once (11,144 B per row at D = 768)")
+        sc.close()
+        del Xd
     except Exception as e:
         out["store_error"] = repr(e)[:300]
     try:
@@ -332,6 +362,85 @@ def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, hp_h1=No
     return out
 
 
+class _LazyRows:
+    """ids / payloads of a bench collection made on demand (10M payload dicts would be 20 GB of Python objects): the
+    handler's code path -- id and payload looked up per returned row, ScoredPoint built -- is what is timed."""
+
+    def __init__(self, make):
+        self.make = make
+
+    def __getitem__(self, r):
+        return self.make(int(r))
+
+
+def boundary_legs(eng, torch, ix, Q, sp_np, P, local):
+    """The reference's own call shape on the driver record (qdrant_handler.py:269-279 one query per hybrid_search call,
+    Python lists in; :363-372 the query): `latency_b1` = ONE query per call through hx_hybrid_query_host (pageable host
+    buffers in, host buffers out, PCIe-inclusive), tree and H1, median of 50 calls; `host_boundary` = the whole batch
+    through the same entry from numpy buffers, and through QdrantHandler.hybrid_search_batch from Python lists with
+    payloads attached.  None of this is `value` (which starts with the inputs resident in HBM)."""
+    import asyncio
+    from rag_application_amd import handler as H
+    out = {}
+    Qh = Q.cpu().numpy()
+    qip, qix, qv = sp_np
+    B = Qh.shape[0]
+    hp = {"tree": eng.make_params(P, mode=eng.HX_MODE_TREE), "h1": eng.make_params(P, mode=eng.HX_MODE_H1)}
+    lat = {}
+    for mode in ("tree", "h1"):
+        ts = []
+        for i in range(55):
+            b = (i * 37) % B
+            a, e = int(qip[b]), int(qip[b + 1])
+            one = (Qh[b:b + 1], np.array([0, e - a], np.int64), qix[a:e], qv[a:e])
+            t0 = time.perf_counter()
+            ix.hybrid_query_host(*one, hp[mode])
+            ts.append(time.perf_counter() - t0)
+        ts = sorted(ts[5:])
+        lat[mode] = dict(median_ms=ts[len(ts) // 2] * 1e3, p10_ms=ts[len(ts) // 10] * 1e3, p90_ms=ts[len(ts) * 9 // 10] * 1e3,
+                         calls=len(ts))
+    out["latency_b1"] = dict(what="ONE query per call through hx_hybrid_query_host (the reference's hybrid_search call shape, "
+                                  "qdrant_handler.py:269-279, 363-372): host buffers in and out, PCIe and the host round trips "
+                                  "included; 10M x 768 index; tree = P-mcp limits 100/80/60/100/40/100/10, h1 = 100 (+) 100 -> 10",
+                             **lat)
+    hb = {}
+    for mode in ("h1", "tree"):
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ix.hybrid_query_host(Qh, qip, qix, qv, hp[mode])
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[len(ts) // 2]
+        hb[f"abi_{mode}"] = dict(ms_per_batch=t * 1e3, queries_per_sec=B / t)
+    # the handler: Python lists in (what the reference's callers hold), ScoredPoint objects with payloads out
+    h = H.QdrantHandler(device=local)
+    col = H._Collection(ix.dim, ix.msizes, local, index=ix)
+    col.ids = _LazyRows(lambda r: f"00000000-0000-4000-8000-{r:012x}")
+    col.payloads = _LazyRows(lambda r: {"content": f"chunk {r}", "file_name": f"doc{r >> 6}.txt", "page_number": r & 63,
+                                        "chunk_number": r & 63, "document_summary": "", "context": None})
+    h._collections["bench"] = col
+    dense_lists = Qh.tolist()
+    sparse_dicts = [{"indices": qix[qip[b]:qip[b + 1]].tolist(), "values": qv[qip[b]:qip[b + 1]].tolist()} for b in range(B)]
+    for name, dv in (("handler_from_python_lists", dense_lists), ("handler_from_ndarray", Qh)):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = asyncio.run(h.hybrid_search_batch("bench", dv, sparse_dicts, top_k=10, search_params=P, mode="h1"))
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[1]
+        hb[name] = dict(ms_per_batch=t * 1e3, queries_per_sec=B / t, results=sum(len(r) for r in res))
+    t0 = time.perf_counter()
+    np.asarray(dense_lists, dtype=np.float32)
+    hb["list_to_ndarray_ms"] = (time.perf_counter() - t0) * 1e3
+    hb["what"] = (f"B = {B} through hx_hybrid_query_host from pageable numpy buffers (abi_*), and through "
+                  "QdrantHandler.hybrid_search_batch (mode h1) with ScoredPoint + payload per returned row; payloads come from a lazy "
+                  "per-row provider (10M dicts do not fit a bench); `list_to_ndarray_ms` = the cost of packing B x 768 Python "
+                  "floats alone")
+    h._collections.pop("bench")          # (the index belongs to the caller)
+    out["host_boundary"] = hb
+    return out
+
+
 def cfg4_shard_leg(eng, synth, torch, local, tabs, Q, sp_q, hp, B, sel, dim, check, share_note, share=0):
     """BASELINE config 4 = 100M x 768 row-sharded over 8 GPUs = 12.5M rows per GPU.  One such shard (rank 0's: rows
     [0, 12.5M) of the same generator, with its postings) on this one GPU: the H1 step every rank would run before the
@@ -377,8 +486,84 @@ def cfg4_shard_leg(eng, synth, torch, local, tabs, Q, sp_q, hp, B, sel, dim, che
     return out
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): this process starts N fresh copies
+    of itself, one rank per GPU, relays rank 0's JSON line and exits with the first non-zero code of a child.  It
+    never imports torch and never touches HIP itself (a parent that had initialised the GPU could not hand it to
+    children safely); the device count comes from a short-lived child.  Fewer visible devices than N is an error line,
+    not a silent rehearsal -- ranks share GPUs only under the explicit HX_DIST_BACKEND=gloo."""
+    import subprocess
+    n = args.gpus
+    backend = os.environ.get("HX_DIST_BACKEND", "nccl")
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=600)
+        ndev = int(out.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001
+        ndev = -1
+        print(f"[bench] could not count devices: {e!r}", file=sys.stderr)
+    if backend == "nccl" and ndev < n:
+        print(json.dumps({"metric": "queries/sec, 10M x 768 hybrid dense+BM25 (RRF top-10)", "value": None,
+                          "unit": "queries/sec", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+                          "error": f"--gpus {n} but {ndev} HIP device(s) visible; one rank per GPU over RCCL needs {n} "
+                                   "(rehearsal on fewer GPUs: HX_DIST_BACKEND=gloo)"}), flush=True)
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    limit = float(os.environ.get("HX_BENCH_TIMEOUT", "3000"))
+    t0, rc, line = time.time(), 0, None
+    import threading
+    got = []
+    rd = threading.Thread(target=lambda: got.extend(procs[0].stdout.readlines()), daemon=True)
+    rd.start()
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0:
+                    rc = c
+                    print(f"[bench] rank {r} exited with code {c}", file=sys.stderr)
+        if time.time() - t0 > limit:
+            rc = 124
+            print(f"[bench] ranks still running after {limit:.0f} s: killed", file=sys.stderr)
+        if live and rc == 0:
+            time.sleep(0.2)
+    for r in live:               # a failed or timed-out job: the exact children started here, by pid
+        procs[r].kill()
+    for p_ in procs:
+        p_.wait()
+    rd.join(timeout=5)
+    for ln in got:
+        if ln.lstrip().startswith("{"):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    if line:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("[bench] rank 0 printed no result line", file=sys.stderr)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     share, share_note = host_share()
     if args.cpu_threads > 0:
         share, share_note = args.cpu_threads, f"--cpu-threads {args.cpu_threads}"
@@ -417,8 +602,14 @@ def main():
     ix = eng.HxIndex(dim, (64, 128, 256), device=local, id_base=r0)
     ix.reserve(r1 - r0)
     ix.synth_fill(r1 - r0, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs)
-    ix.finalize()
     torch.cuda.synchronize()
+    # K9 (the on-device inverted-index build) on its own: HIP events on the stream it runs on, generation excluded
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_a.record()
+    ix.finalize()
+    ev_b.record()
+    torch.cuda.synchronize()
+    k9_ms = ev_a.elapsed_time(ev_b)
     t_build = time.perf_counter() - t_build
 
     # ---- queries, resident in HBM ------------------------------------------------------
@@ -448,6 +639,11 @@ def main():
     # the three header words of a batch travel over a host-side group: over RCCL reading them would park the host
     # behind the previous batch's kernels and the device would idle while it catches up (sharded.bcast_queries)
     hdr_group = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
+    # ... and the payload over a communicator of its own: ProcessGroupNCCL runs one group's collectives in order on one
+    # internal stream, so on the stages' group broadcast(i + 1) would queue behind all-gather(i), which waits for the
+    # local stage of batch i -- the exchange would sit on the critical path of every step instead of beside it
+    bq_group = dist.new_group(backend="nccl") if (world > 1 and backend == "nccl") else None
+    host_group = hdr_group          # a host-side group for decisions all ranks must take alike (gloo: the default group)
 
     def step():
         if world == 1:
@@ -455,7 +651,7 @@ def main():
                 return ix.hybrid_query(Q, qip_d, qix_d, qv_d, hp)    # whole pipeline behind one ABI call
             return sh.search_dense(Q, 10)
         q, ip, ixx, vv = bcast_queries(Q, *((qip_d, qix_d, qv_d) if mode == "h1" else (empty_sp if rank == 0 else (None,) * 3)),
-                                       src=0, device=dev, header_group=hdr_group)
+                                       src=0, group=bq_group, device=dev, header_group=hdr_group)
         if mode == "h1":
             if pipe is not None:
                 return pipe.submit(q, ip, ixx, vv)
@@ -463,17 +659,27 @@ def main():
         return sh.search_dense(q, 10)
 
     pipe_note = None
+    werr = None
     try:
         for _ in range(args.warmup):
             step()
         if pipe is not None:
             pipe.wait()
     except Exception as e:      # noqa: BLE001
-        # N > 1 only: an error every rank sees alike in the pipelined exchange (it has run over gloo and over RCCL with one
-        # rank only) must not cost the line -- fall back to the synchronous exchange and say so
+        werr = e
+    if world > 1:
+        # The decision is COLLECTIVE: an exception on one rank only would otherwise leave the ranks issuing different
+        # collective sequences.  Every rank learns over the host-side group whether any rank failed its warm-up.
+        f = torch.tensor([1 if werr is not None else 0], dtype=torch.int32)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=host_group)
+        if int(f.item()) and werr is None:
+            werr = RuntimeError("another rank failed its warm-up")
+    if werr is not None:
+        # N > 1 only: an error in the pipelined exchange must not cost the line -- every rank falls back to the
+        # synchronous exchange together and the line says so; without a pipeline there is nothing to fall back to
         if pipe is None:
-            raise
-        pipe_note = repr(e)[:300]
+            raise werr
+        pipe_note = repr(werr)[:300]
         pipe = None
         torch.cuda.synchronize()
         for _ in range(args.warmup):
@@ -518,7 +724,7 @@ def main():
                   quantized_limit=40, sparse_limit=50, final_limit=30, hnsw_ef=128)
 
         def tree_step():
-            q, ip, ixx, vv = bcast_queries(Q, qip_d, qix_d, qv_d, src=0, device=dev, header_group=hdr_group)
+            q, ip, ixx, vv = bcast_queries(Q, qip_d, qix_d, qv_d, src=0, group=bq_group, device=dev, header_group=hdr_group)
             return sh.hybrid_tree(q, ip, ixx, vv, Pt)
 
         try:        # (a failure here must not cost the line its main measurement, which is complete at this point)
@@ -604,6 +810,21 @@ def main():
             side = secondary(eng, synth, torch, ix, wl, tabs, Q, (qip_d, qix_d, qv_d) if mode == "h1" else None,
                              local, hp_tree, hp, res)
             side["ingest"] = ingest_leg(eng, synth, torch, local, t_build, rows, st_main["nnz"], tabs)
+            # K9 against SURVEY 8(d)'s formula: nnz * 8 B * 2 (read + write) * passes of the sort over the postings
+            k9_passes = int(st_main.get("sort_passes", 0)) or 4
+            k9_bytes = float(st_main["nnz"]) * 8.0 * 2.0 * k9_passes
+            side["ingest"]["index_build_1e9" if rows == WORKLOADS["cfg3"]["rows"] else "index_build"] = dict(
+                kernel="K9 build_sparse_index (spbuild.hip): term-major postings + per-(term, segment) offsets from the "
+                       "document-major CSR", postings=st_main["nnz"], ms=k9_ms, sort_passes=k9_passes,
+                alg_gb=k9_bytes / 1e9, gbs=k9_bytes / k9_ms / 1e6, frac_of_hbm_peak=k9_bytes / k9_ms / 1e6 / PEAK_HBM_GBS,
+                bound="hbm", peak_gbs=PEAK_HBM_GBS, chunks_per_sec=rows / (k9_ms / 1e3),
+                note="HIP events around hx_finalize on the first build of the timed index (generation of the synthetic "
+                     "corpus excluded); bytes = nnz * 8 * 2 * sort passes (SURVEY 8d)")
+            if mode == "h1":
+                try:
+                    side.update(boundary_legs(eng, torch, ix, Q, (qip, qix, qv), P, local))
+                except Exception as e:      # noqa: BLE001
+                    side["boundary_error"] = repr(e)[:300]
             if mode == "h1" and args.workload == "cfg3" and not args.rows:
                 # BASELINE config 4's per-GPU shape on this one GPU: the 10M index is freed first
                 ix.close()

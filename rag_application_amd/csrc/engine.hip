@@ -294,9 +294,11 @@ static void prep_rows_device(hx_index* h, const float* raw_dev, int64_t n, hipSt
     a.pre[p] = h->pre[p] + h->n * h->psize[p];
   }
   a.pre_h0 = h->n_pre > 0 ? h->pre_h0 + h->n * h->psize[0] : nullptr;
-  a.q8s = h->cand8 ? h->q8s + h->n * h->dim_pad8 : nullptr;
-  a.q8s_scale = h->cand8 ? h->q8s_scale + h->n : nullptr;
-  a.err_max = h->s8_err;
+  const bool c8 = h->cand8 && h->q8s && h->q8s_scale && h->s8_err;   // (never an offset from a null base)
+  HX_CHECK(!h->cand8 || c8, "int8 candidate copy enabled but not allocated");
+  a.q8s = c8 ? h->q8s + h->n * h->dim_pad8 : nullptr;
+  a.q8s_scale = c8 ? h->q8s_scale + h->n : nullptr;
+  a.err_max = c8 ? h->s8_err : nullptr;
   // K1/K2 of SURVEY 8(d): the raw row read once, every derived copy written once
   double per_row = (double)h->dim * 4 + (double)h->dim_pad * 6 + (double)h->dim_pad8 * (h->cand8 ? 2 : 1) + (h->cand8 ? 8 : 4);
   for (int p = 0; p < h->n_pre; ++p) per_row += (double)h->psize[p] * 4;
@@ -2132,7 +2134,21 @@ int hx_set_dense_candidates(hx_index* h, int32_t kind) {
   HX_CHECK(h, "index is NULL");
   HX_CHECK(kind == 0 || kind == 1, "kind: 0 = fp16 candidates, 1 = int8 candidates");
   HX_CHECK(kind == 0 || h->q8s || h->n == 0, "this index holds no int8 candidate copy (created with HX_DENSE_CAND=f16)");
-  if (kind == 1 && !h->q8s) h->cand8 = 1;     // empty index: the copy is made as rows arrive
+  if (kind == 1 && !h->q8s) {                 // empty index: the copy is made as rows arrive
+    // ... into buffers that must exist for the capacity the index already has (hx_reserve, or hx_truncate(h, 0) on an
+    // index created under HX_DENSE_CAND=f16): reserve_rows returns early while want <= cap and would never make them
+    h->set_device();
+    if (h->cap > 0) {
+      grow_copy(h->q8s, 0, h->cap * h->dim_pad8, false);
+      grow_copy(h->q8s_scale, 0, h->cap + 256, true);
+    }
+    if (!h->s8_err) {
+      HX_HIP(hipMalloc((void**)&h->s8_err, 4));
+      HX_HIP(hipMemset(h->s8_err, 0, 4));
+    }
+    h->tm_q8s.rows = -1;
+    h->cand8 = 1;
+  }
   h->cand8_off = kind == 0;
   HX_CATCH
 }
@@ -2360,10 +2376,18 @@ int hx_load(const char* path, int32_t device, hx_index** out) {
       HX_HIP(hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost));
       HX_HIP(hipMemcpy(&hn_long, n_long, 4, hipMemcpyDeviceToHost));
       HX_CHECK(hbad == 0, "corrupt index file: a sparse vector repeats a term id");
-      HX_CHECK(hn_long <= LONG_CAP, "corrupt index file: too many oversized sparse vectors");
-      if (hn_long > 0) {            // the few rows too long for the wave compare: sorted on the host
-        std::vector<int64_t> rows((size_t)hn_long);
-        HX_HIP(hipMemcpy(rows.data(), long_rows, rows.size() * 8, hipMemcpyDeviceToHost));
+      if (hn_long > 0) {            // the rows too long for the wave compare: sorted on the host
+        std::vector<int64_t> rows;
+        if (hn_long <= LONG_CAP) {
+          rows.resize((size_t)hn_long);
+          HX_HIP(hipMemcpy(rows.data(), long_rows, rows.size() * 8, hipMemcpyDeviceToHost));
+        } else {                    // more of them than the device list holds (hx_add_sparse accepts any number): find
+                                    // them all from the offsets -- a valid file, not a corrupt one
+          std::vector<int64_t> ip((size_t)hd.sp_rows + 1);
+          HX_HIP(hipMemcpy(ip.data(), h->sp_indptr, ip.size() * 8, hipMemcpyDeviceToHost));
+          for (int64_t r = 0; r < hd.sp_rows; ++r)
+            if (ip[(size_t)r + 1] - ip[(size_t)r] > CSR_UNIQUE_WAVE_MAX) rows.push_back(r);
+        }
         std::vector<int32_t> ids;
         for (int64_t r : rows) {
           int64_t be[2];

@@ -11,15 +11,6 @@
 
 namespace hx {
 
-__device__ __forceinline__ float wave_bcast_sum_sq(const float* v, int nchunks, int lane) {
-  float p = 0.0f;
-  for (int j = 0; j < nchunks; ++j) p = __fadd_rn(p, __fmul_rn(v[j], v[j]));
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) p = __fadd_rn(p, __shfl_down(p, off, 64));
-  p = __fadd_rn(p, 0.0f);
-  return __shfl(p, 0, 64);
-}
-
 // numpy (x86) float64 -> int8 cast of x*127: truncate, wrap through int32; 0 when
 // |t| >= 2^31 or t is NaN (tests/golden/i8_kat.json pins this).
 __device__ __forceinline__ int8_t quant_i8(float x) {
@@ -291,19 +282,28 @@ __global__ __launch_bounds__(256) void k_prep_queries_f(const float* q_raw, int 
       for (int j = 0; j < nch; ++j) qh[(int64_t)b * dpad + (j << 6) + lane] = (_Float16)0.0f;
     return;
   }
-  float v[MAXCH];
-#pragma unroll 4
+  // Two passes over the raw query (768 floats: L1 after the first) instead of a per-thread array indexed by a
+  // run-time chunk count, which hipcc kept in scratch (272 B per lane; the same pattern k_prep_rows lost in round 3).
+  // Lane l accumulates the squares of elements 64 j + l for ascending j: spec_dot's order.
+  const float* src = q_raw + (int64_t)b * q_dim;
+  float p = 0.0f;
   for (int j = 0; j < nch; ++j) {
     const int c = (j << 6) + lane;
-    v[j] = c < d ? q_raw[(int64_t)b * q_dim + c] : 0.0f;
+    const float x = c < d ? src[c] : 0.0f;
+    p = __fadd_rn(p, __fmul_rn(x, x));
   }
-  const float len2 = wave_bcast_sum_sq(v, nch, lane);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) p = __fadd_rn(p, __shfl_down(p, off, 64));
+  p = __fadd_rn(p, 0.0f);
+  const float len2 = __shfl(p, 0, 64);
   const bool keep = keep_unnormalised(len2);
   const float ln = sqrt_f32_rn(len2);
   for (int j = 0; j < nch; ++j) {
-    const float o = keep ? v[j] : div_f32_rn(v[j], ln);
-    qn[(int64_t)b * dpad + (j << 6) + lane] = o;
-    if (qh) qh[(int64_t)b * dpad + (j << 6) + lane] = (_Float16)o;
+    const int c = (j << 6) + lane;
+    const float x = c < d ? src[c] : 0.0f;
+    const float o = keep ? x : div_f32_rn(x, ln);
+    qn[(int64_t)b * dpad + c] = o;
+    if (qh) qh[(int64_t)b * dpad + c] = (_Float16)o;
   }
 }
 void launch_prep_queries_f(const float* q_raw, int q_dim, int B, int Bpad, int d, int dpad, float* qn,

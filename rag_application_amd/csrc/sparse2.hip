@@ -159,6 +159,9 @@ __device__ __forceinline__ uint32_t sp_wavescan(uint32_t v) {
 // is consumed in that order (sprescore.hip); intermediate cuts need no order at all.
 // Precondition: acc is all zero and every wave is past its last acc access.
 __device__ __forceinline__ void sp_cut(uint64_t* cand, int limit, int M, int tid, bool final) {
+  // (opaque copy of the thread index: hipcc otherwise hoists the eight 64-bit key addresses of this cut out of the
+  // visit loop -- 16 VGPRs held across every visit, which is what made the kernel spill)
+  asm volatile("" : "+v"(tid));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's appends have left the core
   __syncthreads();                                   // ... and every other wave's; S.cnt settled
   int n = S.cnt;

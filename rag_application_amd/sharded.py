@@ -52,6 +52,11 @@ class ShardError(RuntimeError):
     """A call failed on some rank (or a rank did not answer in time): it failed on every rank."""
 
 
+class ShardOutOfStep(ShardError):
+    """A collective step itself failed (a rank died or timed out inside the deal of a batch): the ranks no longer
+    agree on where they are, so the handler that owns the group closes (searches return [], mutations raise)."""
+
+
 def _dev_of(group) -> torch.device:
     if dist.is_initialized() and dist.get_backend(group) == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
@@ -147,6 +152,13 @@ class ShardedCollection:
         self.cdev = _dev_of(group)
         self.dev = device if device is not None else self.cdev
         self.ctl = ctl if ctl is not None else _control_group(group)
+        # C2 gets a communicator of its own over RCCL: ProcessGroupNCCL runs a group's collectives in order on one
+        # internal stream, so the broadcast of batch i + 1 issued on the stages' group would queue behind the
+        # all-gather of batch i (collective: every rank makes it here, in the same order)
+        self.bgroup = group
+        if dist.is_initialized() and self.world > 1 and dist.get_backend(group) == "nccl":
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            self.bgroup = dist.new_group(ranks=ranks, backend="nccl")
         if local is None:
             if index_factory is None:
                 from . import engine as _engine
@@ -225,7 +237,7 @@ class ShardedCollection:
             else:
                 mine_dense, mine_sp = self._deal_arrays(dense, sp_indptr, sp_idx, sp_val, cut, has_sp)
         except Exception as e:                # a broken deal leaves the ranks out of step: nothing to salvage here
-            raise ShardError(f"rank {r}: dealing the batch failed: {e}") from e
+            raise ShardOutOfStep(f"rank {r}: dealing the batch failed: {e}") from e
         # ---- derive + index locally (K1/K2 on ingest, K9 on the next search); a failure is reported, not raised yet
         try:
             if is_text and m:
@@ -318,7 +330,7 @@ class ShardedCollection:
         if head[0] == "refused":
             raise ShardError("query batch refused by the front rank: " + head[1])
         params, mode, rrf_k, rank_base, rrf_limit = head
-        q, ip, ix, v = bcast_queries(q, q_indptr, q_idx, q_val, self.src, self.group, self.dev,
+        q, ip, ix, v = bcast_queries(q, q_indptr, q_idx, q_val, self.src, self.bgroup, self.dev,
                                      header_group=self.ctl if self.world > 1 else None)
         if mode == "h1":
             out = self.sh.hybrid_h1(q, ip, ix, v, params["dense_limit"], params["sparse_limit"], params["final_limit"],
@@ -370,6 +382,9 @@ class _ShardedBackend:
         died or timed out) -- the ranks are out of step from then on and the handler closes"""
         try:
             return fn()
+        except ShardOutOfStep as e:
+            self.h.broken = f"{e}; the sharded handler is closed"
+            raise
         except (ShardError, ValueError, KeyError, TypeError):
             raise
         except Exception as e:
@@ -500,6 +515,10 @@ class ShardedHandler(QdrantHandler):
                     self._save_shard(self._shards[user], meta)
                 elif op == "delete":
                     self._shards.pop(user).close()
+            except ShardOutOfStep as e:       # a collective step itself failed: this rank leaves the loop too
+                self.broken = f"{e}; the sharded handler is closed"
+                logging.error("sharded handler, rank %d: %s", self.rank, self.broken)
+                return
             except Exception as e:
                 logging.error("sharded handler, rank %d: %s(%s) failed: %s", self.rank, op, user, e)
 
@@ -541,7 +560,11 @@ class ShardedHandler(QdrantHandler):
             outs = [err]
             if self.world > 1:
                 outs = [None] * self.world
-                dist.all_gather_object(outs, err, group=self.ctl)
+                try:
+                    dist.all_gather_object(outs, err, group=self.ctl)
+                except Exception as e:        # timeout / lost peer inside the exchange: out of step, as in _command
+                    self.broken = f"a rank did not answer ({type(e).__name__}: {e}); the sharded handler is closed"
+                    raise ShardOutOfStep(self.broken) from e
             bad = [f"rank {j}: {o}" for j, o in enumerate(outs) if o is not None]
             if bad:
                 if local is not None and hasattr(local, "close"):

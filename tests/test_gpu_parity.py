@@ -1439,6 +1439,36 @@ def test_int8_candidate_copy_survives_save_load_and_truncate(eng, torch_mod, tmp
         i.close()
 
 
+def test_int8_candidates_switched_on_after_reserve_or_truncate(eng, torch_mod, monkeypatch):
+    """An index created WITHOUT the int8 candidate copy (HX_DENSE_CAND=f16) that already has capacity -- hx_reserve, or
+    hx_truncate(h, 0) after rows -- and is then switched to int8 candidates: the copy's buffers must exist before the
+    next add writes through them (round 3: reserve_rows returned early and k_prep_rows stored through base-less
+    pointers).  Two adds (the second at a non-zero row offset), then the lists equal the fp16-nominated ones."""
+    n, dim, B, L = 70000, 192, 40, 20
+    X = O.synth_dense(61, 0, n, dim)
+    Qd = torch_mod.from_numpy(O.synth_dense(62, 0, B, dim)).cuda()
+    monkeypatch.setenv("HX_DENSE_CAND", "f16")
+    a = eng.HxIndex(dim, ())
+    b = eng.HxIndex(dim, ())
+    monkeypatch.delenv("HX_DENSE_CAND")
+    assert a.stats()["bytes_i8_cand"] == 0
+    a.reserve(n)                      # capacity without the copy
+    a.set_dense_candidates("i8")
+    b.add(X[:1000])                   # rows, then rolled back to none: capacity stays
+    b.truncate(0)
+    b.set_dense_candidates("i8")
+    for ix in (a, b):
+        ix.add(X[:66000])             # two 65536-row chunks inside one add, then a second add
+        ix.add(X[66000:])
+        assert ix.stats()["bytes_i8_cand"] > 0
+        k8, c8 = ix.search_dense(Qd, L)
+        assert ix.stats()["cand8_queries"] == B
+        ix.set_dense_candidates("f16")
+        k16, c16 = ix.search_dense(Qd, L)
+        assert torch_mod.equal(k8, k16) and torch_mod.equal(c8, c16)
+        ix.close()
+
+
 # ---- the query tree without per-stage host round trips (deferred flags) --------------------------------------------------
 def test_tree_stages_deferred_flags(eng, torch_mod, synth_tables, monkeypatch):
     """(a) hx_search_*_async return the synchronous stages' keys and leave the flag word at 0 on a benign batch;
