@@ -1364,6 +1364,32 @@ def test_load_refuses_a_repeated_term_id(eng, torch_mod, synth_tables, tmp_path)
     ix.close()
 
 
+def test_save_load_many_oversized_sparse_vectors(eng, torch_mod, tmp_path):
+    """More than 4096 sparse vectors of more than 2048 terms (the device's list of rows too long for the wave compare
+    holds 4096): hx_add_sparse accepts them through its host check, so hx_load must too -- save then load is closed for
+    every collection the add path can build (round 3 refused the file as corrupt)."""
+    n, dim, T = 4200, 64, 2049
+    X = O.synth_dense(71, 0, n, dim)
+    ip = np.arange(n + 1, dtype=np.int64) * T
+    rng = np.random.default_rng(72)
+    si = (np.tile(np.arange(T, dtype=np.int64) * 37, n) + np.repeat(rng.integers(0, 1000, n), T) * 100000).astype(np.int32)
+    sv = np.ones(n * T, np.float32)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X, ip, si, sv)
+    path = str(tmp_path / "long.hx")
+    ix.save(path)
+    ld = eng.HxIndex.load(path)
+    assert ld.count() == n and ld.stats()["nnz"] == n * T
+    qip = torch_mod.tensor([0, 2], dtype=torch_mod.int64).cuda()
+    qsi = torch_mod.tensor([37, 74], dtype=torch_mod.int32).cuda()
+    qsv = torch_mod.tensor([1.0, 2.0], dtype=torch_mod.float32).cuda()
+    k0, c0 = ix.search_sparse(qip, qsi, qsv, 10)
+    k1, c1 = ld.search_sparse(qip, qsi, qsv, 10)
+    assert torch_mod.equal(k0, k1) and torch_mod.equal(c0, c1)
+    ix.close()
+    ld.close()
+
+
 # ---- the dense stage's int8 candidate pass (per-row-scaled copy + data-dependent certificate) ------------------------------
 @pytest.mark.parametrize("n,dim,B,L", [(30000, 768, 9, 10), (30000, 768, 300, 100), (20000, 384, 257, 10), (9000, 100, 40, 50),
                                        (40000, 1024, 130, 200)])
