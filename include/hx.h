@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define HX_ABI_VERSION 2   /* 2: hx_set_next_id, hx_add_rows_dev, hx_truncate; max_terms dropped from two entries */
+#define HX_ABI_VERSION 3   /* 2: hx_set_next_id, hx_add_rows_dev, hx_truncate; max_terms dropped from two entries
+                            * 3: the candidates-first sharded H1 (hx_h1_plan / _nominate_async / _rescore_async /
+                            *    _finish), hx_sparse_wmax / hx_set_sparse_wmax */
 
 typedef struct hx_index hx_index;
 
@@ -212,6 +214,44 @@ int hx_h1_local_async(hx_index* h, const float* q_dev, const int64_t* q_indptr_d
 int hx_h1_fuse(int32_t device, const uint64_t* gathered_dev, int32_t world, int32_t B,
                int32_t dense_limit, int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base,
                uint64_t* keys_dev, int32_t* counts_dev, void* stream);
+/* Row-sharded H1 with the exchange BEFORE the exact scores ("candidates first").  What a shard
+ * repeats per QUERY whatever its row count -- the exact re-score of L' dense candidates, the exact re-score of the sparse
+ * margin set, the compaction of full-size buffers -- is divided by the number of shards: a shard only nominates.
+ * Three calls around two collectives per batch, everything enqueued (no host round trip):
+ *  hx_h1_plan            list sizes for `world` shards: k1 / k2 = dense / sparse nominations per shard and query (its
+ *                        binomial share of the global lists + 10 sigma), lp = L' (the global dense candidate count the
+ *                        certificate needs for dense_limit), ks = the global sparse list (top-L + ties within the margin);
+ *  hx_h1_nominate_async  nom_dev [B*k1 dense keys | B*k2 sparse keys | B*2 meta words]: the shard's best k1 rows by the
+ *                        int8 candidate score (hx_search_dense's candidate pass, no exact score) and its best k2
+ *                        documents by the integer BM25 score of the select pass (sparse2.hip), ids global;
+ *                        -> all-gather of nom_dev over the shards;
+ *  hx_h1_rescore_async   gathered_dev [world x B*(k1+k2+2)]: the global candidate lists (top-lp by int8 score, top-ks by
+ *                        integer score), the check that no shard's list was cut above the global cut, and the EXACT
+ *                        scores (spec_dot; upstream-order fp32 sparse sum) of THIS shard's rows among them, at their
+ *                        positions in res_dev [B*lp | B*ks | B*5 meta] (0 elsewhere);
+ *                        -> all-reduce (SUM, as int64) of res_dev: every key slot has one owner, the others hold 0; the
+ *                        five meta words per query are the same on every rank and come back multiplied by `world`;
+ *  hx_h1_finish          reduced_dev: exact dense top-dense_limit with the certificate m + eps < e_L evaluated once on the
+ *                        global list, exact sparse top-sparse_limit, RRF as hx_rrf.  *nfail_dev += queries whose lists
+ *                        are not final (a shard's list was cut too short, a buffer overflowed, the certificate does not
+ *                        hold): the caller then redoes the batch through hx_h1_local, as after hx_h1_local_async.
+ * The integer BM25 scores of different shards are comparable only under one scale: hx_set_sparse_wmax gives every shard
+ * the largest document weight of ANY shard (hx_sparse_wmax reads the shard's own; also whether it holds a non-positive
+ * weight).  Needs the int8 candidate copy (the default). */
+int hx_h1_plan(int32_t dense_limit, int32_t sparse_limit, int32_t world, int32_t* k1, int32_t* k2, int32_t* lp,
+               int32_t* ks);
+int hx_sparse_wmax(hx_index* h, float* wmax, int32_t* nonpos);
+int hx_set_sparse_wmax(hx_index* h, float wmax);
+int hx_h1_nominate_async(hx_index* h, const float* q_dev, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
+                         const float* q_val_dev, int32_t B, int32_t dense_limit, int32_t sparse_limit, int32_t k1,
+                         int32_t k2, uint64_t* nom_dev, void* stream);
+int hx_h1_rescore_async(hx_index* h, const float* q_dev, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
+                        const float* q_val_dev, int32_t B, const uint64_t* gathered_dev, int32_t world,
+                        int32_t dense_limit, int32_t sparse_limit, int32_t k1, int32_t k2, int32_t lp, int32_t ks,
+                        uint64_t* res_dev, void* stream);
+int hx_h1_finish(int32_t device, const uint64_t* reduced_dev, int32_t world, int32_t B, int32_t lp, int32_t ks, int32_t dense_limit,
+                 int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base, uint64_t* keys_dev,
+                 int32_t* counts_dev, int32_t* nfail_dev, void* stream);
 /* keys -> (fp32 score, int64 id); empty slots give (-inf, -1) */
 int hx_unpack(int32_t device, const uint64_t* keys_dev, int64_t n, float* scores_dev,
               int64_t* ids_dev, void* stream);

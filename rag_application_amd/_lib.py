@@ -79,6 +79,15 @@ _SIGS = {
     "hx_h1_local_async": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P],
     "hx_h1_fuse": [C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                    _P, _P, _P],
+    "hx_h1_plan": [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                   C.POINTER(C.c_int32)],
+    "hx_sparse_wmax": [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
+    "hx_set_sparse_wmax": [_P, C.c_float],
+    "hx_h1_nominate_async": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P],
+    "hx_h1_rescore_async": [_P, _P, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                            C.c_int32, C.c_int32, _P, _P],
+    "hx_h1_finish": [C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                     C.c_int32, _P, _P, _P, _P],
     "hx_unpack": [C.c_int32, _P, C.c_int64, _P, _P, _P],
     "hx_hybrid_query_host": [_P, _P, _P, _P, _P, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
     "hx_hybrid_query_dev": [_P, _P, _P, _P, _P, C.c_int32, C.POINTER(HxParams), _P, _P, _P],
@@ -115,7 +124,7 @@ def lib() -> C.CDLL:
             f.restype = C.c_int
         l.hx_last_error.argtypes = []
         l.hx_last_error.restype = C.c_char_p
-        if l.hx_abi_version() != 2:
+        if l.hx_abi_version() != 3:
             raise HxError("libhx ABI version mismatch")
         _lib = l
     return _lib

@@ -12,7 +12,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libhx.so")
 # (source, object, extra defines): sparse2.hip is built for both segment sizes (kernels.hpp)
 SOURCES = [("scan.hip", "scan.o", ()), ("scan8.hip", "scan8.o", ()), ("select.hip", "select.o", ()),
-           ("prep.hip", "prep.o", ()),
+           ("prep.hip", "prep.o", ()), ("shardx.hip", "shardx.o", ()),
            ("sparse2.hip", "sparse2_v32k.o", ("HX_SP_VARIANT=v32k", "HX_SEG_DOCS=32768", "HX_SP_THREADS=512")),
            ("sparse2.hip", "sparse2_v64k.o", ("HX_SP_VARIANT=v64k", "HX_SEG_DOCS=65536", "HX_SP_THREADS=1024")),
            ("sprescore.hip", "sprescore.o", ()),

@@ -152,6 +152,7 @@ struct hx_index {
   int sp_cut_step = 0;                // HX_DEBUG_SP_CUTSTEP (diagnostics): keys between cuts of the select pass, 0 = default
   int64_t tail_min_force = -1;        // HX_DEBUG_TAIL_MIN (tests): documents a tail may hold before the base is rebuilt
   float sp_wmin = 0.f, sp_wmax = 0.f; // range of the document weights (all finite: checked at ingest)
+  float sp_wmax_shared = 0.f;         // hx_set_sparse_wmax: the largest weight of any shard of the collection (0: unset)
   bool sp_have_w = false;
   int64_t sparse_fallbacks = 0;       // queries served by the document-at-a-time path
   Workspace ws;
@@ -431,10 +432,10 @@ static void remap_out(hx_index* h, uint64_t* keys, int64_t n, hipStream_t st) {
                    (uint32_t)h->id_base, (uint32_t)h->n, 1, st);
 }
 // candidate keys a stage takes in: global ids -> internal ids (rows of other shards become empty slots)
-static const uint64_t* remap_in(hx_index* h, const uint64_t* keys, int64_t n, hipStream_t st) {
+static const uint64_t* remap_in(hx_index* h, const uint64_t* keys, int64_t n, hipStream_t st, int slot = WS_ID_IN) {
   if (n <= 0 || ids_identity(h)) return keys;
   ids_upload(h);
-  uint64_t* tmp = (uint64_t*)h->ws.get(WS_ID_IN, (size_t)n * 8);
+  uint64_t* tmp = (uint64_t*)h->ws.get(slot, (size_t)n * 8);
   launch_remap_ids(keys, tmp, n, h->ids.dev, h->ids.dev + h->ids.dev_cap, (int)h->ids.row0.size(),
                    (uint32_t)h->id_base, (uint32_t)h->n, 0, st);
   return tmp;
@@ -504,19 +505,22 @@ static int cand8_lprime(int L) {
   static const int add = getenv("HX_DEBUG_CAND8_ADD") ? std::max(0, atoi(getenv("HX_DEBUG_CAND8_ADD"))) : 288;
   return std::min(std::max(mul2 * L / 2, L + add), std::max(L, CAND_CAP / 4));
 }
-static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false) {
-  static thread_local std::map<std::tuple<int, bool, bool, bool>, Geometry> cache;
-  const auto key = std::make_tuple(L, approx, safe, cand8);
+// lp_force > 0 (with cand8): keep exactly that many candidates -- a shard of the candidates-first H1 exchange nominates
+// its share of the global L', not L' of its own (hx_h1_nominate_async)
+static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false, int lp_force = 0) {
+  static thread_local std::map<std::tuple<int, bool, bool, bool, int>, Geometry> cache;
+  const auto key = std::make_tuple(L, approx, safe, cand8, lp_force);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   Geometry g;
   g.Lp = approx ? L + std::max(32, L / 2) : L;
-  if (cand8) g.Lp = cand8_lprime(L);
+  if (cand8) g.Lp = lp_force > 0 ? lp_force : cand8_lprime(L);
   if (safe) g.Lp = std::min(std::max(2 * g.Lp, g.Lp + 256), CAND_CAP / 4);
   int c = next_pow2(std::max(8 * g.Lp, 1024));
   if (cand8) {
     static const int cmin = getenv("HX_DEBUG_CAND8_C") ? atoi(getenv("HX_DEBUG_CAND8_C")) : 4096;
-    c = std::max(c, cmin);
+    static const int cmin_n = getenv("HX_DEBUG_NOM_C") ? atoi(getenv("HX_DEBUG_NOM_C")) : 2048;
+    c = std::max(c, lp_force > 0 ? cmin_n : cmin);
   }
   g.C = safe ? CAND_CAP : std::min(c, CAND_CAP);
   HX_CHECK(g.Lp * 2 <= g.C && g.Lp >= L, "limit too large");
@@ -996,18 +1000,31 @@ static SparseCsr csr_of(const hx_index* h) {
 // K7: select (integer pass over the inverted index, base and tail) -> exact scores of the kept candidates
 // -> top-L.  Everything is enqueued; sparse_resolve() then reads the per-query flags and serves the flagged
 // queries document-at-a-time.
-static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
-                           int B, int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
+// the select pass of a batch: per query one list of integer-score keys, best first (the top-L plus the documents within
+// the margin of the L-th), stride `lout`
+struct SparseLists {
+  uint64_t* list = nullptr;
+  int* lcnt = nullptr;
+  int lout = 0;
+  int* margin = nullptr;
+  int* flag = nullptr;     // per query: k_sparse_prep's verdict (0 ok)
+  int* fail = nullptr;     // per query: a buffer of the select pass overflowed
+};
+static SparseLists sparse_select_lists(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
+                                       int B, int L, hipStream_t st) {
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   finalize(h, st);
   Workspace& w = h->ws;
+  SparseLists out;
   int* flag = (int*)w.get(WS_SP_FLAG, (size_t)B * 4);
   int* fail = (int*)w.get(WS_SP_FAIL, (size_t)B * 4);
+  out.flag = flag;
+  out.fail = fail;
   HX_HIP(hipMemsetAsync(flag, 0, (size_t)B * 4, st));
   HX_HIP(hipMemsetAsync(fail, 0, (size_t)B * 4, st));
   const hx_index::SparseIx* ixs[2] = {&h->sp_base, &h->sp_tail};
-  if (h->sp_base.n_segments == 0 && h->sp_tail.n_segments == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
+  if (h->sp_base.n_segments == 0 && h->sp_tail.n_segments == 0) return out;     // no posting: list stays NULL
   const int lout = sparse_lout(L);
   // ---- per-query preparation
   SparsePrepArgs pa{};
@@ -1019,7 +1036,7 @@ static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* 
     pa.ix[v] = view_of(h, *ixs[v]);
     pa.q_ti[v] = (int32_t*)w.get(v == 0 ? WS_SP_TI0 : WS_SP_TI1, (size_t)B * SP_TMAX * 4);
   }
-  pa.wmax = h->sp_wmax;
+  pa.wmax = std::max(h->sp_wmax, h->sp_wmax_shared);   // (shared: the largest weight of ANY shard, hx_set_sparse_wmax)
   pa.index_nonpos = (h->sp_have_w && h->sp_wmin > 0.0f) ? 0 : 1;
   pa.q_qs = (float*)w.get(WS_SP_QS, (size_t)B * SP_TMAX * 4);
   pa.q_margin = (int*)w.get(WS_SP_MARGIN, (size_t)B * 4);
@@ -1102,17 +1119,32 @@ static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* 
     list = pk;     // the sorted union goes back to the (now free) parts buffer, stride lout
     launch_compact(packed, pt * lout, lcnt, B, lout, 0, list, lout, lcnt, nullptr, pt * lout, st);
   }
+  out.list = list;
+  out.lcnt = lcnt;
+  out.lout = lout;
+  out.margin = pa.q_margin;
+  return out;
+}
+
+static void sparse_enqueue(hx_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
+                           int B, int L, uint64_t* out_keys, int* out_cnt, hipStream_t st) {
+  const SparseLists sl = sparse_select_lists(h, q_indptr, q_idx, q_val, B, L, st);
+  if (!sl.list) return zero_outputs(out_keys, out_cnt, B, L, st);
+  Workspace& w = h->ws;
+  const int lout = sl.lout;
+  int* flag = sl.flag;
+  int* fail = sl.fail;
   SparseRescoreArgs ra{};
   ra.d = csr_of(h);
   ra.q_indptr = q_indptr;
   ra.q_idx = q_idx;
   ra.q_val = q_val;
-  ra.cand = list;
-  ra.cnt = lcnt;
+  ra.cand = sl.list;
+  ra.cnt = sl.lcnt;
   ra.stride = lout;
   ra.B = B;
   ra.limit = L;
-  ra.q_margin = pa.q_margin;
+  ra.q_margin = sl.margin;
   ra.q_flag = flag;
   ra.out = (uint64_t*)w.get(WS_SP_EXACT, (size_t)B * lout * 8);
   ra.out_cnt = (int*)w.get(WS_SP_ECNT, (size_t)B * 4);
@@ -2018,6 +2050,220 @@ int hx_h1_fuse(int32_t device, const uint64_t* gathered, int32_t world, int32_t 
   launch_regroup(gathered, world, B, dense_limit, sparse_limit, dall, sall, st);
   launch_compact(dall, ds, nullptr, B, dense_limit, 0, D, dense_limit, Dc, nullptr, ds, st);
   launch_compact(sall, ss, nullptr, B, sparse_limit, 0, S, sparse_limit, Sc, nullptr, ss, st);
+  rrf(nullptr, D, dense_limit, Dc, S, sparse_limit, Sc, B, rrf_k, rank_base, limit, keys_dev, counts_dev, st, w);
+  HX_CATCH
+}
+
+// ---- row-sharded H1, candidates first (hx.h; shardx.hip) -----------------------------------------------------------------
+// Workspace slots of the rescore step: it runs on the exchange stream BESIDE the next batch's nominate step on the same
+// index, so it shares no buffer with any other entry.
+enum { WSX = 3000 };
+
+int hx_h1_plan(int32_t dense_limit, int32_t sparse_limit, int32_t world, int32_t* k1, int32_t* k2, int32_t* lp,
+               int32_t* ks) {
+  HX_TRY
+  HX_CHECK(k1 && k2 && lp && ks, "NULL argument");
+  HX_CHECK(dense_limit >= 1 && dense_limit <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= MAX_LIMIT, "limit out of range [1, 2048]");
+  HX_CHECK(world >= 1 && world <= 64, "world out of range [1, 64]");
+  // a shard's share of the global L' candidates is Binomial(L', 1/world) on exchangeable rows: mean + 10 sigma (+ 8),
+  // to a multiple of 32; a topically clustered collection trips the completeness check instead and the caller widens
+  // the lists (distributed.H1Pipeline doubles them after a redone batch)
+  auto share = [&](int n) {
+    const double p = 1.0 / world, mean = n * p, sd = std::sqrt(n * p * (1.0 - p));
+    return (int)std::min<int64_t>(round_up((int64_t)std::ceil(mean + 10.0 * sd + 8.0), 32), round_up(n, 32));
+  };
+  const int Lp = cand8_lprime(dense_limit);
+  HX_CHECK(Lp <= MAX_LIMIT, "dense_limit too large for the candidates-first exchange");
+  *lp = Lp;
+  *k1 = std::min(share(Lp), CAND_CAP / world / 32 * 32);
+  const int Ks = (int)round_up(sparse_limit + sparse_limit / 2 + 64, 64);      // the global margin set: L + the ties
+  *ks = std::min(Ks, MAX_LIMIT);
+  *k2 = std::min(std::max(64, 2 * share(sparse_limit + 32)), CAND_CAP / world / 32 * 32);
+  HX_CHECK(*k1 >= 32 && *k2 >= 32, "world too large for the candidates-first exchange");
+  HX_CATCH
+}
+
+int hx_sparse_wmax(hx_index* h, float* wmax, int32_t* nonpos) {
+  HX_TRY
+  HX_CHECK(h && wmax && nonpos, "NULL argument");
+  *wmax = h->sp_have_w ? h->sp_wmax : 0.0f;
+  *nonpos = (h->sp_have_w && !(h->sp_wmin > 0.0f)) ? 1 : 0;
+  HX_CATCH
+}
+
+int hx_set_sparse_wmax(hx_index* h, float wmax) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  HX_CHECK(wmax >= 0.0f && wmax <= SPARSE_ABS_MAX, "wmax out of range");
+  h->sp_wmax_shared = wmax;
+  HX_CATCH
+}
+
+int hx_h1_nominate_async(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix, const float* qv, int32_t B,
+                         int32_t dense_limit, int32_t sparse_limit, int32_t k1, int32_t k2, uint64_t* nom_dev,
+                         void* stream) {
+  HX_TRY
+  HX_CHECK(h && qd && qip && nom_dev && B > 0, "bad argument");
+  HX_CHECK(dense_limit >= 1 && dense_limit <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= MAX_LIMIT, "limit out of range [1, 2048]");
+  HX_CHECK(k1 >= 1 && k1 <= CAND_CAP / 4 && k2 >= 1 && k2 <= sparse_lout(sparse_limit), "k1 / k2 out of range");
+  h->set_device();
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& w = h->ws;
+  // ---- dense: the shard's best k1 rows by the int8 candidate score (no exact score here)
+  uint64_t* cand = nullptr;
+  int *cnt = nullptr, *ovf = nullptr;
+  float* eq = nullptr;
+  int cstride = 0;
+  if (h->n > 0) {
+    HX_CHECK(h->cand8 && !h->cand8_off && h->q8s, "the candidates-first exchange needs the int8 candidate copy");
+    const MatrixRef m = pick_matrix(h, 0);
+    const int bn = scan_bn(B);
+    const int Bpad = (int)round_up(B, bn);
+    float* qn = (float*)w.get(WS_QN, (size_t)B * m.dpad * 4);
+    launch_prep_queries_f(qd, h->dim, B, B, m.d, m.dpad, qn, nullptr, st);
+    const Geometry g = geometry(dense_limit, true, false, true, k1);
+    cand = (uint64_t*)w.get(WS_CAND, (size_t)B * g.C * 8);
+    cnt = (int*)w.get(WS_CNT, (size_t)B * 4);
+    ovf = (int*)w.get(WS_OVF, (size_t)B * 4);
+    float* tau = (float*)w.get(WS_TAU, (size_t)B * 4);
+    int8_t* q8 = (int8_t*)w.get(WS_Q8S, (size_t)Bpad * h->dim_pad8);
+    float* sq = (float*)w.get(WS_SQ, (size_t)Bpad * 4);
+    eq = (float*)w.get(WS_EPSQ, (size_t)B * 4);
+    launch_prep_queries_s8(qn, m.dpad, B, Bpad, h->dim_pad8, q8, sq, eq, h->s8_err, st);
+    chunked_scan(h, KIND_I8, (const uint8_t*)h->q8s, (const uint8_t*)q8, h->dim_pad8, B, bn, g, cand, cnt, ovf, tau, sq, st,
+                 h->q8s_scale, &h->tm_q8s, 3);
+    cstride = g.C;
+    h->cand8_queries += B;
+    remap_out(h, cand, (int64_t)B * g.C, st);        // (identity for a shard filled in one block: skipped)
+  }
+  // ---- sparse: the shard's integer-score list (the select pass only)
+  const SparseLists sl = sparse_select_lists(h, qip, qix, qv, B, sparse_limit, st);
+  h->sp_sum_pending = false;                         // nobody will call sparse_resolve for this batch
+  h->sp_sum_fetched = false;
+  if (sl.list) remap_out(h, sl.list, (int64_t)B * sl.lout, st);
+  launch_h1x_pack(cand, cstride, cnt, ovf, eq, h->n <= k1 ? 1 : 0, k1, sl.list, sl.lout, sl.lcnt, sl.flag, sl.fail, k2,
+                  std::max(h->sp_wmax, h->sp_wmax_shared), B, nom_dev, st);
+  HX_CATCH
+}
+
+int hx_h1_rescore_async(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix, const float* qv, int32_t B,
+                        const uint64_t* gathered_dev, int32_t world, int32_t dense_limit, int32_t sparse_limit, int32_t k1,
+                        int32_t k2, int32_t lp, int32_t ks, uint64_t* res_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(h && qd && qip && gathered_dev && res_dev && B > 0 && world >= 1, "bad argument");
+  HX_CHECK(dense_limit >= 1 && dense_limit <= lp && lp <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= ks && ks <= MAX_LIMIT,
+           "limits out of range");
+  HX_CHECK((int64_t)world * k1 <= CAND_CAP && (int64_t)world * k2 <= CAND_CAP && k1 >= 1 && k2 >= 1, "world x k out of range [1, 8192]");
+  h->set_device();
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& w = h->ws;
+  const int du_s = world * k1, su_s = world * k2;
+  uint64_t* du = (uint64_t*)w.get(WSX + 1, (size_t)B * du_s * 8);
+  uint64_t* su = (uint64_t*)w.get(WSX + 2, (size_t)B * su_s * 8);
+  uint64_t* G = (uint64_t*)w.get(WSX + 3, (size_t)B * lp * 8);
+  int* gc = (int*)w.get(WSX + 4, (size_t)B * 4);
+  uint64_t* SL = (uint64_t*)w.get(WSX + 5, (size_t)B * ks * 8);
+  int* sc = (int*)w.get(WSX + 6, (size_t)B * 4);
+  int* margin = (int*)w.get(WSX + 7, (size_t)B * 4);
+  int* qflag = (int*)w.get(WSX + 8, (size_t)B * 4);
+  int* spref = (int*)w.get(WSX + 9, (size_t)B * 4);
+  int* sfail = (int*)w.get(WSX + 10, (size_t)B * 4);
+  uint64_t* de = res_dev;                                    // [B x lp]
+  uint64_t* se = res_dev + (size_t)B * lp;                   // [B x ks]
+  uint64_t* meta = res_dev + (size_t)B * (lp + ks);          // [B x 5]
+  HX_HIP(hipMemsetAsync(res_dev, 0, (size_t)B * (lp + ks + 5) * 8, st));
+  HX_HIP(hipMemsetAsync(sfail, 0, (size_t)B * 4, st));
+  HX_HIP(hipMemsetAsync(spref, 0, (size_t)B * 4, st));
+  launch_h1x_union(gathered_dev, world, B, k1, k2, du, su, st);
+  launch_compact(du, du_s, nullptr, B, std::min(lp, du_s), 0, G, lp, gc, nullptr, du_s, st);
+  launch_compact(su, su_s, nullptr, B, std::min(ks, su_s), 0, SL, ks, sc, nullptr, su_s, st);
+  launch_h1x_cuts(gathered_dev, world, B, k1, k2, G, gc, lp, SL, sc, ks, sparse_limit, qip, meta, margin, qflag, st);
+  // ---- this rank's rows among the global candidates: exact spec_dot / exact upstream-order sparse score
+  if (h->n > 0) {
+    const MatrixRef m = pick_matrix(h, 0);
+    float* qn = (float*)w.get(WSX + 11, (size_t)B * m.dpad * 4);
+    launch_prep_queries_f(qd, h->dim, B, B, m.d, m.dpad, qn, nullptr, st);
+    RescoreArgs r{};
+    r.kind = KIND_F32;
+    r.M = m.m32;
+    r.row_stride = m.dpad;
+    r.dim_pad = m.dpad;
+    r.Q = qn;
+    r.q_stride = m.dpad;
+    r.n_rows = h->n;
+    r.id_base = h->id_base;
+    r.cand = remap_in(h, G, (int64_t)B * lp, st, WSX + 12);   // rows of other shards become empty slots
+    r.cnt = gc;
+    r.stride = lp;
+    r.max_cnt = lp;
+    r.B = B;
+    r.out = de;
+    launch_rescore_list(r, st);
+    remap_out(h, de, (int64_t)B * lp, st);
+  }
+  if (h->sp_rows > 0 && h->nnz > 0) {
+    SparseRescoreArgs ra{};
+    ra.d = csr_of(h);
+    ra.q_indptr = qip;
+    ra.q_idx = qix;
+    ra.q_val = qv;
+    ra.cand = remap_in(h, SL, (int64_t)B * ks, st, WSX + 13);
+    ra.cnt = sc;
+    ra.stride = ks;
+    ra.B = B;
+    ra.limit = sparse_limit;
+    ra.q_margin = margin;
+    ra.q_flag = qflag;
+    ra.out = se;
+    ra.out_cnt = spref;
+    ra.q_fail = sfail;
+    launch_sparse_rescore(ra, st);
+    remap_out(h, se, (int64_t)B * ks, st);
+  } else {
+    // a shard without postings scores nothing, but the prefix length is a property of the global list: every rank
+    // reports the same number (the all-reduce takes the maximum)
+    SparseRescoreArgs ra{};
+    ra.d = SparseCsr{nullptr, nullptr, nullptr, 0, h->id_base};
+    ra.q_indptr = qip;
+    ra.q_idx = qix;
+    ra.q_val = qv;
+    ra.cand = SL;
+    ra.cnt = sc;
+    ra.stride = ks;
+    ra.B = B;
+    ra.limit = sparse_limit;
+    ra.q_margin = margin;
+    ra.q_flag = qflag;
+    ra.out = se;
+    ra.out_cnt = spref;
+    ra.q_fail = sfail;
+    launch_sparse_rescore(ra, st);
+  }
+  launch_h1x_fold(spref, sfail, B, meta, st);
+  HX_CATCH
+}
+
+int hx_h1_finish(int32_t device, const uint64_t* reduced_dev, int32_t world, int32_t B, int32_t lp, int32_t ks, int32_t dense_limit,
+                 int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base, uint64_t* keys_dev,
+                 int32_t* counts_dev, int32_t* nfail_dev, void* stream) {
+  HX_TRY
+  HX_CHECK(reduced_dev && keys_dev && counts_dev && nfail_dev && B > 0 && world >= 1, "bad argument");
+  HX_CHECK(dense_limit >= 1 && dense_limit <= lp && lp <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= ks && ks <= MAX_LIMIT,
+           "limits out of range");
+  HX_CHECK(limit >= 1 && limit <= MAX_LIMIT, "limit out of range [1, 2048]");
+  HX_HIP(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& w = static_ws(device);
+  uint64_t* D = (uint64_t*)w.get(WS_F_D, (size_t)B * dense_limit * 8);
+  uint64_t* S = (uint64_t*)w.get(WS_F_S, (size_t)B * sparse_limit * 8);
+  int* Dc = (int*)w.get(WS_F_DC, (size_t)B * 4);
+  int* Sc = (int*)w.get(WS_F_SC, (size_t)B * 4);
+  int* fail = (int*)w.get(WS_FAIL, (size_t)B * 4);
+  uint64_t* de = const_cast<uint64_t*>(reduced_dev);
+  uint64_t* se = de + (size_t)B * lp;
+  launch_compact(de, lp, nullptr, B, dense_limit, 0, D, dense_limit, Dc, nullptr, lp, st);
+  launch_compact(se, ks, nullptr, B, sparse_limit, 0, S, sparse_limit, Sc, nullptr, ks, st);
+  launch_h1x_certify(reduced_dev, world, B, lp, ks, D, Dc, dense_limit, fail, nfail_dev, st);
   rrf(nullptr, D, dense_limit, Dc, S, sparse_limit, Sc, B, rrf_k, rank_base, limit, keys_dev, counts_dev, st, w);
   HX_CATCH
 }

@@ -142,6 +142,18 @@ void launch_flag_add(int* acc, const int* add2, hipStream_t st);   // *acc += ad
 void launch_remap_ids(const uint64_t* in, uint64_t* out, int64_t n, const uint32_t* row0, const uint32_t* gid0, int nb,
                       uint32_t id_base, uint32_t n_rows, int to_global, hipStream_t st);
 
+// ---- shardx.hip: row-sharded H1, candidates exchanged before the exact scores ----------------
+void launch_h1x_pack(const uint64_t* cand, int cstride, const int* cnt, const int* ovf, const float* eps, int complete,
+                     int k1, const uint64_t* list, int lstride, const int* lcnt, const int* sflag, const int* sfail, int k2,
+                     float wmax, int B, uint64_t* nom, hipStream_t st);
+void launch_h1x_union(const uint64_t* g, int world, int B, int k1, int k2, uint64_t* du, uint64_t* su, hipStream_t st);
+void launch_h1x_cuts(const uint64_t* g, int world, int B, int k1, int k2, const uint64_t* G, const int* gc, int lp,
+                     const uint64_t* SL, const int* sc, int ks, int L_s, const int64_t* q_indptr, uint64_t* meta,
+                     int* q_margin, int* q_flag, hipStream_t st);
+void launch_h1x_fold(const int* sp_pref, const int* sp_fail, int B, uint64_t* meta, hipStream_t st);
+void launch_h1x_certify(const uint64_t* red, int world, int B, int lp, int ks, const uint64_t* D, const int* Dc, int L,
+                        int* fail, int* nfail, hipStream_t st);
+
 // ---- prep.hip ----------------------------------------------------------------
 // Derive the stored vectors of rows [0,n) of `raw` (fp32 [n x dim]):
 struct PrepRowsArgs {

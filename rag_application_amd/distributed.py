@@ -73,6 +73,36 @@ class ShardedIndex:
             dist.all_gather_into_tensor(out, keys.contiguous(), group=self.group)
         return out
 
+    def reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place integer sum over the ranks (the exchange of exact keys: one owner per slot, zeros elsewhere)."""
+        if self.world == 1:
+            return t
+        if dist.get_backend(self.group) == "gloo":
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def sync_sparse_scale(self) -> None:
+        """Collective: every shard learns the largest document weight of ANY shard, so that the integer BM25 scores of
+        the select pass mean the same on all of them (the candidates-first exchange compares them across shards).
+        Call after rows were added; a shard whose own maximum has outgrown the shared one is caught at search time
+        (the batch is flagged and redone per shard)."""
+        if not hasattr(self.local, "sparse_wmax"):
+            return
+        w, _ = self.local.sparse_wmax()
+        t = torch.tensor([w], dtype=torch.float32)
+        if self.world > 1:
+            if dist.get_backend(self.group) == "gloo":
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            else:
+                d = t.cuda()
+                dist.all_reduce(d, op=dist.ReduceOp.MAX, group=self.group)
+                t = d.cpu()
+        self.local.set_sparse_wmax(float(t.item()))
+
     def _global(self, keys, limit, dedupe=False):
         if self.world == 1:
             return keys, None
@@ -187,7 +217,7 @@ class H1Pipeline:
     ranks it has run over gloo (CPU tests, 2-4 ranks sharing one GPU).  DESIGN.md section 7 says so."""
 
     def __init__(self, sh: ShardedIndex, dense_limit=100, sparse_limit=100, limit=10, rrf_k=2.0, rank_base=0,
-                 depth: int = 2, force_side_stream: bool = False):
+                 depth: int = 2, force_side_stream: bool = False, candidates_first: Optional[bool] = None):
         self.sh = sh
         self.args = (dense_limit, sparse_limit, limit, rrf_k, rank_base)
         fast = hasattr(sh.local, "h1_local") and hasattr(sh.ops, "h1_fuse")
@@ -197,23 +227,54 @@ class H1Pipeline:
         self.pending = []          # batches whose flags have not been looked at yet, oldest first
         self.redone = 0            # batches that went through the synchronous path after all
         self._pin, self._n = None, 0   # ring of pinned host buffers for the ranks' flag words
+        # Candidates first (hx.h: hx_h1_nominate_async ...): a shard sends its SHARE of the global candidate lists --
+        # int8-scored rows, integer-scored documents -- the exact scores are computed once per candidate by the rank
+        # that owns it, and the certificate is evaluated once on the global list.  Two collectives per batch (an
+        # all-gather of the nominations, an integer-sum all-reduce of the exact keys) instead of one, both beside the
+        # next batch's local stage; what a shard pays per query whatever its row count falls by about the number of
+        # shards.  A batch that a check flags -- a shard's list cut above the global cut (topically clustered rows), an
+        # overflow, a certificate that does not hold -- is redone through the per-shard path, and the lists are widened.
+        cf_ok = (self.deferred and hasattr(sh.local, "h1_nominate_async") and hasattr(sh.ops, "h1_finish")
+                 and hasattr(sh.ops, "h1_plan"))
+        self.cf = cf_ok if candidates_first is None else bool(candidates_first and cf_ok)
+        if self.cf:
+            try:
+                self.k1, self.k2, self.lp, self.ks = sh.ops.h1_plan(dense_limit, sparse_limit, max(sh.world, 1))
+                cap = 8192 // max(sh.world, 1) // 32 * 32       # world x k keys are merged in one 8192-key buffer
+                self.k1max, self.k2max = min(max(self.lp, self.k1), cap), min(max(self.ks, self.k2), cap)
+                sh.sync_sparse_scale()
+            except Exception:          # limits the plan does not take: the per-shard exchange serves them
+                self.cf = False
 
     def _exchange_and_fuse(self, mine, B):
         sh = self.sh
         dl, sl, limit, rrf_k, rank_base = self.args
         g = mine if sh.world == 1 else sh.gather_raw(mine)              # [world * (B + 1), dl + sl], rank-major
         g3 = g.view(sh.world, B + 1, dl + sl)
-        flags = g3[:, B, 0]
-        if flags.is_cuda:
-            if self._pin is None:
-                self._pin = [torch.empty((sh.world,), dtype=flags.dtype, pin_memory=True) for _ in range(self.depth + 2)]
-            host = self._pin[self._n % len(self._pin)]     # (more buffers than batches ever pending)
-            self._n += 1
-            host.copy_(flags, non_blocking=True)
-        else:
-            host = flags.clone()
+        host = self._pinned(g3[:, B, 0])
         out = sh.ops.h1_fuse(g3[:, :B, :].reshape(sh.world * B, dl + sl), sh.world, dl, sl, limit, rrf_k, rank_base)
         return out, host
+
+    def _pinned(self, flags):
+        if flags.is_cuda:
+            n = max(self.sh.world, 1)
+            if self._pin is None:
+                self._pin = [torch.zeros((n,), dtype=torch.int64, pin_memory=True) for _ in range(self.depth + 2)]
+            host = self._pin[self._n % len(self._pin)][:flags.numel()]     # (more buffers than batches ever pending)
+            self._n += 1
+            host.copy_(flags, non_blocking=True)
+            return host
+        return flags.clone()
+
+    def _exchange_candidates_first(self, nom, inputs, B):
+        sh = self.sh
+        dl, sl, limit, rrf_k, rank_base = self.args
+        k1, k2, lp, ks = self._cfk
+        g = nom if sh.world == 1 else sh.gather_raw(nom.view(1, -1)).view(-1)       # [world * B * (k1 + k2 + 2)]
+        res = sh.local.h1_rescore_async(*inputs, g, sh.world, dl, sl, k1, k2, lp, ks)
+        sh.reduce_sum(res)
+        keys, cnt, nfail = sh.ops.h1_finish(res, sh.world, B, lp, ks, dl, sl, limit, rrf_k, rank_base)
+        return (keys, cnt), self._pinned(nfail.to(torch.int64))
 
     def submit(self, q, q_indptr, q_idx, q_val):
         sh = self.sh
@@ -221,20 +282,30 @@ class H1Pipeline:
         if not self.deferred:
             return sh.hybrid_h1(q, q_indptr, q_idx, q_val, dl, sl, limit, rrf_k, rank_base)
         B = q.shape[0]
-        mine = sh.local.h1_local_async(q, q_indptr, q_idx, q_val, dl, sl)      # enqueued; no host round trip
+        cf = self.cf
+        if cf:
+            self._cfk = (self.k1, self.k2, self.lp, self.ks)
+            mine = sh.local.h1_nominate_async(q, q_indptr, q_idx, q_val, dl, sl, self.k1, self.k2)
+        else:
+            mine = sh.local.h1_local_async(q, q_indptr, q_idx, q_val, dl, sl)      # enqueued; no host round trip
         done = None
         if self.side is not None:
             ready = torch.cuda.Event()
             ready.record()
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
-                out, host = self._exchange_and_fuse(mine, B)
+                if cf:
+                    out, host = self._exchange_candidates_first(mine, (q, q_indptr, q_idx, q_val), B)
+                else:
+                    out, host = self._exchange_and_fuse(mine, B)
                 done = torch.cuda.Event()
                 done.record()
             mine.record_stream(self.side)
             main = torch.cuda.current_stream()
             for t in out:                       # made on the side stream, consumed on the submitting one
                 t.record_stream(main)
+        elif cf:
+            out, host = self._exchange_candidates_first(mine, (q, q_indptr, q_idx, q_val), B)
         else:
             out, host = self._exchange_and_fuse(mine, B)
         self.pending.append((done, host, (q, q_indptr, q_idx, q_val), out))
@@ -254,6 +325,10 @@ class H1Pipeline:
             out[0].copy_(k)
             out[1].copy_(c)
             self.redone += 1
+            if self.cf:             # (the same decision on every rank: the flag words are the same)
+                if self.k1 >= self.k1max and self.k2 >= self.k2max:
+                    self.cf = False     # full-length lists were still not enough: the per-shard exchange from here on
+                self.k1, self.k2 = min(2 * self.k1, self.k1max), min(2 * self.k2, self.k2max)
 
     def wait(self):
         while self.pending:

@@ -266,6 +266,45 @@ class HxIndex:
                                            sparse_limit, _ptr(keys), _stream()))
         return keys
 
+    # -- candidates-first sharded H1 (hx.h: hx_h1_nominate_async / hx_h1_rescore_async; distributed.H1Pipeline) ----------
+    def sparse_wmax(self):
+        """(largest document weight of this shard, whether it holds a non-positive weight)"""
+        w, npos = C.c_float(), C.c_int32()
+        check(_lib.lib().hx_sparse_wmax(self._h, C.byref(w), C.byref(npos)))
+        return float(w.value), bool(npos.value)
+
+    def set_sparse_wmax(self, wmax: float):
+        """The largest document weight of ANY shard: one scale for the integer BM25 scores of all shards."""
+        check(_lib.lib().hx_set_sparse_wmax(self._h, float(wmax)))
+
+    def h1_nominate_async(self, q, q_indptr, q_idx, q_val, dense_limit: int, sparse_limit: int, k1: int, k2: int):
+        """This shard's nominations, flat [B * (k1 + k2 + 2)] (hx_h1_nominate_async)."""
+        q = _need_cuda(q, torch.float32, "q")
+        q_indptr = _need_cuda(q_indptr, torch.int64, "q_indptr")
+        q_idx = _need_cuda(q_idx, torch.int32, "q_idx")
+        q_val = _need_cuda(q_val, torch.float32, "q_val")
+        B = q.shape[0]
+        nom = torch.empty((B * (k1 + k2 + 2),), dtype=torch.int64, device=q.device)
+        check(_lib.lib().hx_h1_nominate_async(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, dense_limit,
+                                              sparse_limit, k1, k2, _ptr(nom), _stream()))
+        return nom
+
+    def h1_rescore_async(self, q, q_indptr, q_idx, q_val, gathered: torch.Tensor, world: int, dense_limit: int,
+                         sparse_limit: int, k1: int, k2: int, lp: int, ks: int):
+        """Exact scores of this shard's rows among the global candidates, flat [B * (lp + ks + 5)] (hx_h1_rescore_async)."""
+        q = _need_cuda(q, torch.float32, "q")
+        q_indptr = _need_cuda(q_indptr, torch.int64, "q_indptr")
+        q_idx = _need_cuda(q_idx, torch.int32, "q_idx")
+        q_val = _need_cuda(q_val, torch.float32, "q_val")
+        gathered = _need_cuda(gathered, torch.int64, "gathered")
+        B = q.shape[0]
+        if gathered.numel() != world * B * (k1 + k2 + 2):
+            raise HxError("gathered nominations have the wrong size")
+        res = torch.empty((B * (lp + ks + 5),), dtype=torch.int64, device=q.device)
+        check(_lib.lib().hx_h1_rescore_async(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, _ptr(gathered),
+                                             world, dense_limit, sparse_limit, k1, k2, lp, ks, _ptr(res), _stream()))
+        return res
+
     def rescore(self, q: torch.Tensor, cand_keys: torch.Tensor, cand_counts: Optional[torch.Tensor],
                 limit: int, prefix: int = 0):
         q = _need_cuda(q, torch.float32, "q")
@@ -330,6 +369,28 @@ def h1_fuse(gathered: torch.Tensor, world: int, dense_limit: int, sparse_limit: 
     check(_lib.lib().hx_h1_fuse(dev.index or 0, _ptr(gathered), world, B, dense_limit, sparse_limit, limit, k,
                                 rank_base, _ptr(keys), _ptr(cnt), _stream()))
     return keys, cnt
+
+
+def h1_plan(dense_limit: int, sparse_limit: int, world: int):
+    """(k1, k2, lp, ks) of the candidates-first exchange for `world` shards (hx_h1_plan)."""
+    v = [C.c_int32() for _ in range(4)]
+    check(_lib.lib().hx_h1_plan(dense_limit, sparse_limit, world, *[C.byref(x) for x in v]))
+    return tuple(int(x.value) for x in v)
+
+
+def h1_finish(reduced: torch.Tensor, world: int, B: int, lp: int, ks: int, dense_limit: int, sparse_limit: int, limit: int = 10,
+              k: float = 2.0, rank_base: int = 0, nfail: Optional[torch.Tensor] = None):
+    """reduced: the all-reduced (integer sum over the `world` ranks) result of h1_rescore_async.  Returns (keys [B, limit], counts [B], nfail [1]):
+    nfail = queries whose lists are not final (hx_h1_finish adds to it)."""
+    dev = reduced.device
+    reduced = reduced.contiguous()
+    keys = torch.empty((B, limit), dtype=torch.int64, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    if nfail is None:
+        nfail = torch.zeros((1,), dtype=torch.int32, device=dev)
+    check(_lib.lib().hx_h1_finish(dev.index or 0, _ptr(reduced), world, B, lp, ks, dense_limit, sparse_limit, limit, k, rank_base,
+                                  _ptr(keys), _ptr(cnt), _ptr(nfail), _stream()))
+    return keys, cnt, nfail
 
 
 def merge(keys_in: torch.Tensor, counts_in: Optional[torch.Tensor], limit: int, dedupe: bool = False):

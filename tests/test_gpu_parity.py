@@ -485,6 +485,135 @@ def test_two_shards_one_gpu_merge_equals_unsharded(eng, torch_mod, synth_tables)
         s.close()
 
 
+def _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, limit, k1, k2, lp, ks):
+    """The candidates-first H1 exchange by hand on one GPU: nominate on every shard, the all-gather = cat, rescore on
+    every shard, the integer-sum all-reduce = sum, finish.  Returns (keys, counts, failed queries)."""
+    W, B = len(shards), Qd.shape[0]
+    g = torch_mod.cat([s.h1_nominate_async(Qd, *tq, dl, sl, k1, k2) for s in shards])
+    res = [s.h1_rescore_async(Qd, *tq, g, W, dl, sl, k1, k2, lp, ks) for s in shards]
+    red = torch_mod.stack(res).sum(dim=0)
+    k, c, nf = eng.h1_finish(red, W, B, lp, ks, dl, sl, limit)
+    return k, c, int(nf.item())
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_candidates_first_exchange_equals_one_index(eng, torch_mod, synth_tables, world):
+    """hx_h1_nominate_async / hx_h1_rescore_async / hx_h1_finish (row-sharded H1, the exchange before the exact scores)
+    against ONE index over the same rows and against the oracle: ids and score bits, with duplicate rows on different
+    shards (a tie the global list must order by id) and duplicate documents (equal sparse scores)."""
+    n, dim, B, dl, sl = 24000, 256, 130, 40, 25
+    tabs = synth_tables
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, tabs)
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    per = n // world
+    for b in range(6):                        # a near neighbour of query b, copied into every shard: dense ties
+        for r in range(world):
+            X[r * per + 100 + b] = Q[b] + 0.01 * X[b]
+    for r in range(1, world):                 # document 7 of shard 0 repeated in every shard: sparse ties
+        a0, a1 = ip[7], ip[8]
+        d = r * per + 7
+        assert ip[d + 1] - ip[d] >= 1
+        m = min(a1 - a0, ip[d + 1] - ip[d])
+        si[ip[d]:ip[d] + m] = si[a0:a0 + m]
+        sv[ip[d]:ip[d] + m] = sv[a0:a0 + m]
+        if ip[d + 1] - ip[d] > m:             # (keep the row's ids unique: push the rest out of the vocabulary's way)
+            si[ip[d] + m:ip[d + 1]] = 2 ** 30 + np.arange(ip[d + 1] - ip[d] - m)
+    ora = O.OracleIndex(dim, ())
+    ora.add(X, ip, si, sv)
+    ora.finalize()
+    one = eng.HxIndex(dim, ())
+    one.add(X, ip, si.astype(np.int32), sv)
+    shards = []
+    for r in range(world):
+        r0, r1 = r * per, (r + 1) * per if r + 1 < world else n
+        ix = eng.HxIndex(dim, (), id_base=r0)
+        ix.add(X[r0:r1], ip[r0:r1 + 1] - ip[r0], si[ip[r0]:ip[r1]].astype(np.int32), sv[ip[r0]:ip[r1]])
+        shards.append(ix)
+    wmax = max(s.sparse_wmax()[0] for s in shards)
+    for s in shards:
+        s.set_sparse_wmax(wmax)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, tabs)
+    qsi[qip[0]:qip[0] + 1] = si[ip[7]]        # query 0 asks for a term of the repeated document
+    o = np.argsort(qsi[qip[0]:qip[1]], kind="stable")
+    qsi[qip[0]:qip[1]] = qsi[qip[0]:qip[1]][o]
+    qsv[qip[0]:qip[1]] = qsv[qip[0]:qip[1]][o]
+    keep = np.ones(len(qsi), bool)            # (strictly ascending ids within query 0)
+    keep[qip[0] + 1:qip[1]] = np.diff(qsi[qip[0]:qip[1]]) > 0
+    cnt = np.add.reduceat(keep.astype(np.int64), qip[:-1]) if len(qsi) else np.zeros(B, np.int64)
+    qsi, qsv = qsi[keep], qsv[keep]
+    qip = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
+    k1, k2, lp, ks = eng.h1_plan(dl, sl, world)
+    assert k1 < lp and k1 % 32 == 0 and k2 % 32 == 0 and lp >= dl and ks >= sl
+    k, c, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, ks)
+    assert nf == 0
+    s_, i_, c_ = unpack_np(eng, k, c)
+    hp = eng.make_params(dict(P_MCP, dense_limit=dl, sparse_limit=sl, final_limit=10), mode=eng.HX_MODE_H1)
+    s1, i1, c1 = unpack_np(eng, *one.hybrid_query(Qd, *tq, hp))
+    for b in range(B):
+        assert_list_equal(s_[b], i_[b], c_[b], s1[b, :c1[b]], i1[b, :c1[b]], f"candidates first vs one index b={b}")
+        es, ei = O.hybrid_h1(ora, Q[b], qsi[qip[b]:qip[b + 1]], qsv[qip[b]:qip[b + 1]], dl, sl, 10)
+        assert_list_equal(s_[b], i_[b], c_[b], es, ei, f"candidates first vs oracle b={b}")
+    # shards that scale their integer scores differently must be caught, not merged
+    shards[0].set_sparse_wmax(2.0 * wmax)
+    _, _, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, ks)
+    assert nf == B
+    one.close()
+    for s in shards:
+        s.close()
+
+
+def test_candidates_first_flags_what_it_cannot_serve(eng, torch_mod, synth_tables):
+    """The three ways a batch of the candidates-first exchange is NOT final, each caught by hx_h1_finish's count (the
+    caller then redoes the batch per shard): (a) a query whose best rows all live in one shard -- that shard's list is
+    cut above the global cut; (b) rows the int8 grid cannot resolve -- the certificate m + eps < e_L does not hold on
+    the global list; (c) everything else stays final, and the unflagged queries' lists are the single index's."""
+    n, dim, B, dl, sl, world = 16000, 256, 64, 20, 20, 4
+    per = n // world
+    X = O.synth_dense(81, 0, n, dim)
+    Q = O.synth_dense(82, 0, B, dim)
+    k1, k2, lp, ks = eng.h1_plan(dl, sl, world)
+    # (a) queries 0-3: lp near-copies of the query, all in shard 2
+    for b in range(4):                               # (graded: the exact scores spread far wider than the certificate radius)
+        X[2 * per + 500 * b:2 * per + 500 * b + lp] = Q[b] + (0.05 + 0.002 * np.arange(lp, dtype=np.float32))[:, None] * \
+            O.synth_dense(83 + b, 0, lp, dim)
+    # (b) queries 8-11: a tight cluster around the query (scores differ in the 5th digit), dealt over the shards
+    for b in range(8, 12):
+        rows = np.arange(world * 100) % world * per + 3000 + 100 * (b - 8) + np.arange(world * 100) // world
+        X[rows] = Q[b] + 1e-3 * O.synth_dense(90 + b, 0, len(rows), dim)    # 400 rows > lp: the cut lies inside the cluster
+    ip, si, sv = O.synth_sparse_docs(O.SEED_SPDOC, 0, n, synth_tables)
+    qip, qsi, qsv = O.synth_sparse_queries(O.SEED_SPQUERY, 0, B, synth_tables)
+    tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
+    one = eng.HxIndex(dim, ())
+    one.add(X, ip, si.astype(np.int32), sv)
+    shards = []
+    for r in range(world):
+        r0, r1 = r * per, (r + 1) * per
+        ix = eng.HxIndex(dim, (), id_base=r0)
+        ix.add(X[r0:r1], ip[r0:r1 + 1] - ip[r0], si[ip[r0]:ip[r1]].astype(np.int32), sv[ip[r0]:ip[r1]])
+        shards.append(ix)
+    wmax = max(s.sparse_wmax()[0] for s in shards)
+    for s in shards:
+        s.set_sparse_wmax(wmax)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    k, c, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, ks)
+    assert nf >= 8, nf                               # (a) and (b) at least
+    # the flags per query are not part of the ABI's output; the lists of every query OUTSIDE the planted ones must be final
+    hp = eng.make_params(dict(P_MCP, dense_limit=dl, sparse_limit=sl, final_limit=10), mode=eng.HX_MODE_H1)
+    s1, i1, c1 = unpack_np(eng, *one.hybrid_query(Qd, *tq, hp))
+    s_, i_, c_ = unpack_np(eng, k, c)
+    for b in list(range(4, 8)) + list(range(12, B)):
+        assert_list_equal(s_[b], i_[b], c_[b], s1[b, :c1[b]], i1[b, :c1[b]], f"b={b}")
+    # with full-length lists (k1 = lp) nothing is cut: only the certificate failures of (b) remain
+    _, _, nf_full = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, lp - lp % 32 + 32, k2, lp, ks)
+    assert 4 <= nf_full < nf, (nf_full, nf)
+    one.close()
+    for s in shards:
+        s.close()
+
+
 def test_large_batches_go_through_in_slices(eng, torch_mod, synth_tables):
     """hx_hybrid_query_dev with B = 4300 (tree and H1): the engine slices batches beyond 4096 (engine.hip: hybrid_query_dev);
     every row equals the same query asked in a small batch of its own, and a sample equals the oracle."""
