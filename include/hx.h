@@ -218,19 +218,23 @@ int hx_h1_fuse(int32_t device, const uint64_t* gathered_dev, int32_t world, int3
  * repeats per QUERY whatever its row count -- the exact re-score of L' dense candidates, the exact re-score of the sparse
  * margin set, the compaction of full-size buffers -- is divided by the number of shards: a shard only nominates.
  * Three calls around two collectives per batch, everything enqueued (no host round trip):
- *  hx_h1_plan            list sizes for `world` shards: k1 / k2 = dense / sparse nominations per shard and query (its
- *                        binomial share of the global lists + 10 sigma), lp = L' (the global dense candidate count the
- *                        certificate needs for dense_limit), ks = the global sparse list (top-L + ties within the margin);
- *  hx_h1_nominate_async  nom_dev [B*k1 dense keys | B*k2 sparse keys | B*2 meta words]: the shard's best k1 rows by the
- *                        int8 candidate score (hx_search_dense's candidate pass, no exact score) and its best k2
- *                        documents by the integer BM25 score of the select pass (sparse2.hip), ids global;
- *                        -> all-gather of nom_dev over the shards;
- *  hx_h1_rescore_async   gathered_dev [world x B*(k1+k2+2)]: the global candidate lists (top-lp by int8 score, top-ks by
- *                        integer score), the check that no shard's list was cut above the global cut, and the EXACT
- *                        scores (spec_dot; upstream-order fp32 sparse sum) of THIS shard's rows among them, at their
- *                        positions in res_dev [B*lp | B*ks | B*5 meta] (0 elsewhere);
+ *  hx_h1_plan            list sizes for `world` shards: k1 = dense nominations per shard and query (its binomial share of
+ *                        the global L' + 10 sigma), k2 = integer BM25 scores it sends, lp = L' (the global dense
+ *                        candidate count the certificate needs for dense_limit), k3 = exact sparse keys it returns,
+ *                        lout = the stride of its private integer-score list;
+ *  hx_h1_nominate_async  nom_dev [B*k1 dense keys | B*k2 sparse keys | B*2 meta words | B*lout + B private words]: the
+ *                        shard's best k1 rows by the int8 candidate score (hx_search_dense's candidate pass, no exact
+ *                        score) and its k2 best integer BM25 scores of the select pass (sparse2.hip); the private tail
+ *                        (its whole integer-score list) stays on this rank for hx_h1_rescore_async;
+ *                        -> all-gather of the first B*(k1+k2+2) words over the shards;
+ *  hx_h1_rescore_async   gathered_dev [world x B*(k1+k2+2)] + this rank's own nom_dev: the global cuts (top-lp by int8
+ *                        score; the global L-th integer score, hence the margin-set threshold), the check that no
+ *                        shard's list was cut above them, and the EXACT scores (spec_dot; upstream-order fp32 sparse sum)
+ *                        of THIS shard's rows: res_dev [B*lp dense keys at their positions in the global list |
+ *                        B*world*k3 sparse keys, this rank's best k3 in slot `rank` | B*world candidate counts | B*4
+ *                        meta], 0 elsewhere;
  *                        -> all-reduce (SUM, as int64) of res_dev: every key slot has one owner, the others hold 0; the
- *                        five meta words per query are the same on every rank and come back multiplied by `world`;
+ *                        four meta words per query are the same on every rank and come back multiplied by `world`;
  *  hx_h1_finish          reduced_dev: exact dense top-dense_limit with the certificate m + eps < e_L evaluated once on the
  *                        global list, exact sparse top-sparse_limit, RRF as hx_rrf.  *nfail_dev += queries whose lists
  *                        are not final (a shard's list was cut too short, a buffer overflowed, the certificate does not
@@ -239,19 +243,19 @@ int hx_h1_fuse(int32_t device, const uint64_t* gathered_dev, int32_t world, int3
  * the largest document weight of ANY shard (hx_sparse_wmax reads the shard's own; also whether it holds a non-positive
  * weight).  Needs the int8 candidate copy (the default). */
 int hx_h1_plan(int32_t dense_limit, int32_t sparse_limit, int32_t world, int32_t* k1, int32_t* k2, int32_t* lp,
-               int32_t* ks);
+               int32_t* k3, int32_t* lout);
 int hx_sparse_wmax(hx_index* h, float* wmax, int32_t* nonpos);
 int hx_set_sparse_wmax(hx_index* h, float wmax);
 int hx_h1_nominate_async(hx_index* h, const float* q_dev, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
                          const float* q_val_dev, int32_t B, int32_t dense_limit, int32_t sparse_limit, int32_t k1,
                          int32_t k2, uint64_t* nom_dev, void* stream);
 int hx_h1_rescore_async(hx_index* h, const float* q_dev, const int64_t* q_indptr_dev, const int32_t* q_idx_dev,
-                        const float* q_val_dev, int32_t B, const uint64_t* gathered_dev, int32_t world,
-                        int32_t dense_limit, int32_t sparse_limit, int32_t k1, int32_t k2, int32_t lp, int32_t ks,
-                        uint64_t* res_dev, void* stream);
-int hx_h1_finish(int32_t device, const uint64_t* reduced_dev, int32_t world, int32_t B, int32_t lp, int32_t ks, int32_t dense_limit,
-                 int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base, uint64_t* keys_dev,
-                 int32_t* counts_dev, int32_t* nfail_dev, void* stream);
+                        const float* q_val_dev, int32_t B, const uint64_t* nom_dev, const uint64_t* gathered_dev,
+                        int32_t world, int32_t rank, int32_t dense_limit, int32_t sparse_limit, int32_t k1, int32_t k2,
+                        int32_t lp, int32_t k3, uint64_t* res_dev, void* stream);
+int hx_h1_finish(int32_t device, const uint64_t* reduced_dev, int32_t world, int32_t B, int32_t lp, int32_t k3,
+                 int32_t dense_limit, int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base,
+                 uint64_t* keys_dev, int32_t* counts_dev, int32_t* nfail_dev, void* stream);
 /* keys -> (fp32 score, int64 id); empty slots give (-inf, -1) */
 int hx_unpack(int32_t device, const uint64_t* keys_dev, int64_t n, float* scores_dev,
               int64_t* ids_dev, void* stream);

@@ -80,12 +80,12 @@ _SIGS = {
     "hx_h1_fuse": [C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                    _P, _P, _P],
     "hx_h1_plan": [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                   C.POINTER(C.c_int32)],
+                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "hx_sparse_wmax": [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)],
     "hx_set_sparse_wmax": [_P, C.c_float],
     "hx_h1_nominate_async": [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P],
-    "hx_h1_rescore_async": [_P, _P, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                            C.c_int32, C.c_int32, _P, _P],
+    "hx_h1_rescore_async": [_P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                            C.c_int32, C.c_int32, C.c_int32, _P, _P],
     "hx_h1_finish": [C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                      C.c_int32, _P, _P, _P, _P],
     "hx_unpack": [C.c_int32, _P, C.c_int64, _P, _P, _P],

@@ -1308,6 +1308,7 @@ static void rrf(hx_index* h, const uint64_t* a, int as, const int* ac, const uin
   (void)h;
   HX_CHECK(limit >= 1 && limit <= MAX_LIMIT, "rrf limit out of range");
   HX_CHECK(as + bs <= CAND_CAP, "rrf lists too long");
+  if (launch_rrf_top(a, as, ac, b, bs, bc, B, k, base, std::min(limit, as + bs), out_keys, limit, out_cnt, st)) return;
   uint64_t* tmp = (uint64_t*)ws.get(WS_RRF_TMP, (size_t)B * (as + bs) * 8);
   int* tcnt = (int*)ws.get(WS_MISC, (size_t)B * 4);
   launch_rrf(a, as, ac, b, bs, bc, B, k, base, std::min(limit, as + bs), tmp, tcnt, st);
@@ -2060,26 +2061,27 @@ int hx_h1_fuse(int32_t device, const uint64_t* gathered, int32_t world, int32_t 
 enum { WSX = 3000 };
 
 int hx_h1_plan(int32_t dense_limit, int32_t sparse_limit, int32_t world, int32_t* k1, int32_t* k2, int32_t* lp,
-               int32_t* ks) {
+               int32_t* k3, int32_t* lout) {
   HX_TRY
-  HX_CHECK(k1 && k2 && lp && ks, "NULL argument");
+  HX_CHECK(k1 && k2 && lp && k3 && lout, "NULL argument");
   HX_CHECK(dense_limit >= 1 && dense_limit <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= MAX_LIMIT, "limit out of range [1, 2048]");
   HX_CHECK(world >= 1 && world <= 64, "world out of range [1, 64]");
-  // a shard's share of the global L' candidates is Binomial(L', 1/world) on exchangeable rows: mean + 10 sigma (+ 8),
-  // to a multiple of 32; a topically clustered collection trips the completeness check instead and the caller widens
-  // the lists (distributed.H1Pipeline doubles them after a redone batch)
+  // a shard's share of a global list of n is Binomial(n, 1/world) on exchangeable rows: mean + 10 sigma (+ 8), to a
+  // multiple of 32; a topically clustered collection trips the completeness checks instead and the caller widens the
+  // lists (distributed.H1Pipeline doubles them after a redone batch)
   auto share = [&](int n) {
     const double p = 1.0 / world, mean = n * p, sd = std::sqrt(n * p * (1.0 - p));
     return (int)std::min<int64_t>(round_up((int64_t)std::ceil(mean + 10.0 * sd + 8.0), 32), round_up(n, 32));
   };
+  const int cap = CAND_CAP / world / 32 * 32;       // world x k keys are merged in one 8192-key buffer
+  HX_CHECK(cap >= 32, "world too large for the candidates-first exchange");
   const int Lp = cand8_lprime(dense_limit);
   HX_CHECK(Lp <= MAX_LIMIT, "dense_limit too large for the candidates-first exchange");
   *lp = Lp;
-  *k1 = std::min(share(Lp), CAND_CAP / world / 32 * 32);
-  const int Ks = (int)round_up(sparse_limit + sparse_limit / 2 + 64, 64);      // the global margin set: L + the ties
-  *ks = std::min(Ks, MAX_LIMIT);
-  *k2 = std::min(std::max(64, 2 * share(sparse_limit + 32)), CAND_CAP / world / 32 * 32);
-  HX_CHECK(*k1 >= 32 && *k2 >= 32, "world too large for the candidates-first exchange");
+  *k1 = std::min(share(Lp), cap);
+  *k2 = std::min(share(sparse_limit), cap);         // integer scores: enough to fix the value of the global L-th
+  *k3 = std::min(share(sparse_limit), cap);         // exact sparse keys a shard returns
+  *lout = sparse_lout(sparse_limit);
   HX_CATCH
 }
 
@@ -2105,7 +2107,8 @@ int hx_h1_nominate_async(hx_index* h, const float* qd, const int64_t* qip, const
   HX_TRY
   HX_CHECK(h && qd && qip && nom_dev && B > 0, "bad argument");
   HX_CHECK(dense_limit >= 1 && dense_limit <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= MAX_LIMIT, "limit out of range [1, 2048]");
-  HX_CHECK(k1 >= 1 && k1 <= CAND_CAP / 4 && k2 >= 1 && k2 <= sparse_lout(sparse_limit), "k1 / k2 out of range");
+  const int lout = sparse_lout(sparse_limit);
+  HX_CHECK(k1 >= 1 && k1 <= CAND_CAP / 4 && k2 >= 1 && k2 <= lout, "k1 / k2 out of range");
   h->set_device();
   hipStream_t st = (hipStream_t)stream;
   Workspace& w = h->ws;
@@ -2136,49 +2139,61 @@ int hx_h1_nominate_async(hx_index* h, const float* qd, const int64_t* qip, const
     h->cand8_queries += B;
     remap_out(h, cand, (int64_t)B * g.C, st);        // (identity for a shard filled in one block: skipped)
   }
-  // ---- sparse: the shard's integer-score list (the select pass only)
+  // ---- sparse: the shard's integer-score list (the select pass only; ids stay internal: only the scores travel, the
+  // list itself is consumed by this rank's own rescore step)
   const SparseLists sl = sparse_select_lists(h, qip, qix, qv, B, sparse_limit, st);
   h->sp_sum_pending = false;                         // nobody will call sparse_resolve for this batch
   h->sp_sum_fetched = false;
-  if (sl.list) remap_out(h, sl.list, (int64_t)B * sl.lout, st);
+  HX_CHECK(!sl.list || sl.lout == lout, "sparse list stride");
   launch_h1x_pack(cand, cstride, cnt, ovf, eq, h->n <= k1 ? 1 : 0, k1, sl.list, sl.lout, sl.lcnt, sl.flag, sl.fail, k2,
-                  std::max(h->sp_wmax, h->sp_wmax_shared), B, nom_dev, st);
+                  lout, std::max(h->sp_wmax, h->sp_wmax_shared), B, nom_dev, st);
   HX_CATCH
 }
 
 int hx_h1_rescore_async(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix, const float* qv, int32_t B,
-                        const uint64_t* gathered_dev, int32_t world, int32_t dense_limit, int32_t sparse_limit, int32_t k1,
-                        int32_t k2, int32_t lp, int32_t ks, uint64_t* res_dev, void* stream) {
+                        const uint64_t* nom_dev, const uint64_t* gathered_dev, int32_t world, int32_t rank,
+                        int32_t dense_limit, int32_t sparse_limit, int32_t k1, int32_t k2, int32_t lp, int32_t k3,
+                        uint64_t* res_dev, void* stream) {
   HX_TRY
-  HX_CHECK(h && qd && qip && gathered_dev && res_dev && B > 0 && world >= 1, "bad argument");
-  HX_CHECK(dense_limit >= 1 && dense_limit <= lp && lp <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= ks && ks <= MAX_LIMIT,
-           "limits out of range");
-  HX_CHECK((int64_t)world * k1 <= CAND_CAP && (int64_t)world * k2 <= CAND_CAP && k1 >= 1 && k2 >= 1, "world x k out of range [1, 8192]");
+  HX_CHECK(h && qd && qip && nom_dev && gathered_dev && res_dev && B > 0 && world >= 1 && rank >= 0 && rank < world, "bad argument");
+  HX_CHECK(dense_limit >= 1 && dense_limit <= lp && lp <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= MAX_LIMIT, "limits out of range");
+  HX_CHECK((int64_t)world * k1 <= CAND_CAP && (int64_t)world * k2 <= CAND_CAP && (int64_t)world * k3 <= CAND_CAP && k1 >= 1 &&
+               k2 >= 1 && k3 >= 1 && k3 <= 256,
+           "world x k out of range");
   h->set_device();
   hipStream_t st = (hipStream_t)stream;
   Workspace& w = h->ws;
-  const int du_s = world * k1, su_s = world * k2;
+  const int lout = sparse_lout(sparse_limit);
+  const int du_s = world * k1, su_s = world * k2, L_s = sparse_limit;
   uint64_t* du = (uint64_t*)w.get(WSX + 1, (size_t)B * du_s * 8);
   uint64_t* su = (uint64_t*)w.get(WSX + 2, (size_t)B * su_s * 8);
   uint64_t* G = (uint64_t*)w.get(WSX + 3, (size_t)B * lp * 8);
   int* gc = (int*)w.get(WSX + 4, (size_t)B * 4);
-  uint64_t* SL = (uint64_t*)w.get(WSX + 5, (size_t)B * ks * 8);
+  uint64_t* ST = (uint64_t*)w.get(WSX + 5, (size_t)B * L_s * 8);
   int* sc = (int*)w.get(WSX + 6, (size_t)B * 4);
   int* margin = (int*)w.get(WSX + 7, (size_t)B * 4);
   int* qflag = (int*)w.get(WSX + 8, (size_t)B * 4);
-  int* spref = (int*)w.get(WSX + 9, (size_t)B * 4);
+  int* ncand = (int*)w.get(WSX + 9, (size_t)B * 4);
   int* sfail = (int*)w.get(WSX + 10, (size_t)B * 4);
-  uint64_t* de = res_dev;                                    // [B x lp]
-  uint64_t* se = res_dev + (size_t)B * lp;                   // [B x ks]
-  uint64_t* meta = res_dev + (size_t)B * (lp + ks);          // [B x 5]
-  HX_HIP(hipMemsetAsync(res_dev, 0, (size_t)B * (lp + ks + 5) * 8, st));
+  uint32_t* thr = (uint32_t*)w.get(WSX + 14, (size_t)B * 4);
+  int* pcnt = (int*)w.get(WSX + 15, (size_t)B * 4);
+  uint64_t* ex = (uint64_t*)w.get(WSX + 16, (size_t)B * lout * 8);
+  uint64_t* T = (uint64_t*)w.get(WSX + 17, (size_t)B * k3 * 8);
+  int* tc = (int*)w.get(WSX + 18, (size_t)B * 4);
+  const size_t V = (size_t)lp + (size_t)world * k3 + world + 4;
+  uint64_t* de = res_dev;                                          // [B x lp]
+  uint64_t* se = res_dev + (size_t)B * lp;                         // [B x world x k3]
+  uint64_t* nc = se + (size_t)B * world * k3;                      // [B x world]
+  uint64_t* meta = nc + (size_t)B * world;                         // [B x 4]
+  HX_HIP(hipMemsetAsync(res_dev, 0, (size_t)B * V * 8, st));
   HX_HIP(hipMemsetAsync(sfail, 0, (size_t)B * 4, st));
-  HX_HIP(hipMemsetAsync(spref, 0, (size_t)B * 4, st));
+  HX_HIP(hipMemsetAsync(ncand, 0, (size_t)B * 4, st));
+  HX_HIP(hipMemsetAsync(tc, 0, (size_t)B * 4, st));
   launch_h1x_union(gathered_dev, world, B, k1, k2, du, su, st);
   launch_compact(du, du_s, nullptr, B, std::min(lp, du_s), 0, G, lp, gc, nullptr, du_s, st);
-  launch_compact(su, su_s, nullptr, B, std::min(ks, su_s), 0, SL, ks, sc, nullptr, su_s, st);
-  launch_h1x_cuts(gathered_dev, world, B, k1, k2, G, gc, lp, SL, sc, ks, sparse_limit, qip, meta, margin, qflag, st);
-  // ---- this rank's rows among the global candidates: exact spec_dot / exact upstream-order sparse score
+  launch_compact(su, su_s, nullptr, B, std::min(L_s, su_s), 0, ST, L_s, sc, nullptr, su_s, st);
+  launch_h1x_cuts(gathered_dev, world, B, k1, k2, G, gc, lp, ST, sc, L_s, qip, meta, thr, margin, qflag, st);
+  // ---- this rank's rows among the global dense candidates: exact spec_dot at their positions in G
   if (h->n > 0) {
     const MatrixRef m = pick_matrix(h, 0);
     float* qn = (float*)w.get(WSX + 11, (size_t)B * m.dpad * 4);
@@ -2201,54 +2216,43 @@ int hx_h1_rescore_async(hx_index* h, const float* qd, const int64_t* qip, const 
     launch_rescore_list(r, st);
     remap_out(h, de, (int64_t)B * lp, st);
   }
+  // ---- this rank's documents at or above the GLOBAL threshold, from its own list of the nominate step: exact
+  // upstream-order scores, its best k3 into its slot
   if (h->sp_rows > 0 && h->nnz > 0) {
+    const uint64_t* plist = nom_dev + (size_t)B * (k1 + k2 + 2);
+    launch_h1x_counts(plist + (size_t)B * lout, B, pcnt, st);
     SparseRescoreArgs ra{};
     ra.d = csr_of(h);
     ra.q_indptr = qip;
     ra.q_idx = qix;
     ra.q_val = qv;
-    ra.cand = remap_in(h, SL, (int64_t)B * ks, st, WSX + 13);
-    ra.cnt = sc;
-    ra.stride = ks;
+    ra.cand = plist;
+    ra.cnt = pcnt;
+    ra.stride = lout;
     ra.B = B;
     ra.limit = sparse_limit;
     ra.q_margin = margin;
     ra.q_flag = qflag;
-    ra.out = se;
-    ra.out_cnt = spref;
+    ra.out = ex;
+    ra.out_cnt = ncand;
     ra.q_fail = sfail;
+    ra.thr_in = thr;
+    ra.blocks = 4;            // ~ (L + 10) / world candidates per query here, not L + 10
     launch_sparse_rescore(ra, st);
-    remap_out(h, se, (int64_t)B * ks, st);
-  } else {
-    // a shard without postings scores nothing, but the prefix length is a property of the global list: every rank
-    // reports the same number (the all-reduce takes the maximum)
-    SparseRescoreArgs ra{};
-    ra.d = SparseCsr{nullptr, nullptr, nullptr, 0, h->id_base};
-    ra.q_indptr = qip;
-    ra.q_idx = qix;
-    ra.q_val = qv;
-    ra.cand = SL;
-    ra.cnt = sc;
-    ra.stride = ks;
-    ra.B = B;
-    ra.limit = sparse_limit;
-    ra.q_margin = margin;
-    ra.q_flag = qflag;
-    ra.out = se;
-    ra.out_cnt = spref;
-    ra.q_fail = sfail;
-    launch_sparse_rescore(ra, st);
+    launch_compact(ex, lout, ncand, B, std::min(k3, lout), 0, T, k3, tc, nullptr, lout, st);
+    remap_out(h, T, (int64_t)B * k3, st);
   }
-  launch_h1x_fold(spref, sfail, B, meta, st);
+  launch_h1x_place(T, tc, ncand, sfail, B, k3, world, rank, se, nc, meta, st);
   HX_CATCH
 }
 
-int hx_h1_finish(int32_t device, const uint64_t* reduced_dev, int32_t world, int32_t B, int32_t lp, int32_t ks, int32_t dense_limit,
-                 int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base, uint64_t* keys_dev,
-                 int32_t* counts_dev, int32_t* nfail_dev, void* stream) {
+int hx_h1_finish(int32_t device, const uint64_t* reduced_dev, int32_t world, int32_t B, int32_t lp, int32_t k3,
+                 int32_t dense_limit, int32_t sparse_limit, int32_t limit, float rrf_k, int32_t rank_base,
+                 uint64_t* keys_dev, int32_t* counts_dev, int32_t* nfail_dev, void* stream) {
   HX_TRY
   HX_CHECK(reduced_dev && keys_dev && counts_dev && nfail_dev && B > 0 && world >= 1, "bad argument");
-  HX_CHECK(dense_limit >= 1 && dense_limit <= lp && lp <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= ks && ks <= MAX_LIMIT,
+  HX_CHECK(dense_limit >= 1 && dense_limit <= lp && lp <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= MAX_LIMIT && k3 >= 1 &&
+               (int64_t)world * k3 <= CAND_CAP,
            "limits out of range");
   HX_CHECK(limit >= 1 && limit <= MAX_LIMIT, "limit out of range [1, 2048]");
   HX_HIP(hipSetDevice(device));
@@ -2261,9 +2265,10 @@ int hx_h1_finish(int32_t device, const uint64_t* reduced_dev, int32_t world, int
   int* fail = (int*)w.get(WS_FAIL, (size_t)B * 4);
   uint64_t* de = const_cast<uint64_t*>(reduced_dev);
   uint64_t* se = de + (size_t)B * lp;
+  const int ss = world * k3;
   launch_compact(de, lp, nullptr, B, dense_limit, 0, D, dense_limit, Dc, nullptr, lp, st);
-  launch_compact(se, ks, nullptr, B, sparse_limit, 0, S, sparse_limit, Sc, nullptr, ks, st);
-  launch_h1x_certify(reduced_dev, world, B, lp, ks, D, Dc, dense_limit, fail, nfail_dev, st);
+  launch_compact(se, ss, nullptr, B, std::min(sparse_limit, ss), 0, S, sparse_limit, Sc, nullptr, ss, st);
+  launch_h1x_certify(reduced_dev, world, B, lp, k3, D, Dc, dense_limit, S, Sc, sparse_limit, fail, nfail_dev, st);
   rrf(nullptr, D, dense_limit, Dc, S, sparse_limit, Sc, B, rrf_k, rank_base, limit, keys_dev, counts_dev, st, w);
   HX_CATCH
 }

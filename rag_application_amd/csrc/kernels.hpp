@@ -128,6 +128,10 @@ void launch_certify(const uint64_t* approx_keys, int approx_stride, const int* a
 void launch_rrf(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride,
                 const int* b_cnt, int B, float k, int rank_base, int limit, uint64_t* out,
                 int* out_cnt, hipStream_t st);
+// fusion + top-`limit` in one launch when both lists together hold at most 256 keys (returns false otherwise: use
+// launch_rrf + launch_compact); out [B x out_stride], out_cnt [B]
+bool launch_rrf_top(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride, const int* b_cnt,
+                    int B, float k, int rank_base, int limit, uint64_t* out, int out_stride, int* out_cnt, hipStream_t st);
 void launch_unpack(const uint64_t* keys, int64_t n, float* scores, int64_t* ids, hipStream_t st);
 // out[b*(sa+sb) ...] = a-list then b-list (empty slots 0)
 void launch_concat(const uint64_t* a, int a_stride, const int* a_cnt, const uint64_t* b, int b_stride,
@@ -145,14 +149,16 @@ void launch_remap_ids(const uint64_t* in, uint64_t* out, int64_t n, const uint32
 // ---- shardx.hip: row-sharded H1, candidates exchanged before the exact scores ----------------
 void launch_h1x_pack(const uint64_t* cand, int cstride, const int* cnt, const int* ovf, const float* eps, int complete,
                      int k1, const uint64_t* list, int lstride, const int* lcnt, const int* sflag, const int* sfail, int k2,
-                     float wmax, int B, uint64_t* nom, hipStream_t st);
+                     int lout, float wmax, int B, uint64_t* nom, hipStream_t st);
 void launch_h1x_union(const uint64_t* g, int world, int B, int k1, int k2, uint64_t* du, uint64_t* su, hipStream_t st);
 void launch_h1x_cuts(const uint64_t* g, int world, int B, int k1, int k2, const uint64_t* G, const int* gc, int lp,
-                     const uint64_t* SL, const int* sc, int ks, int L_s, const int64_t* q_indptr, uint64_t* meta,
+                     const uint64_t* ST, const int* sc, int L_s, const int64_t* q_indptr, uint64_t* meta, uint32_t* thr_out,
                      int* q_margin, int* q_flag, hipStream_t st);
-void launch_h1x_fold(const int* sp_pref, const int* sp_fail, int B, uint64_t* meta, hipStream_t st);
-void launch_h1x_certify(const uint64_t* red, int world, int B, int lp, int ks, const uint64_t* D, const int* Dc, int L,
-                        int* fail, int* nfail, hipStream_t st);
+void launch_h1x_counts(const uint64_t* priv_cnt, int B, int* out, hipStream_t st);
+void launch_h1x_place(const uint64_t* T, const int* tc, const int* ncand, const int* sp_fail, int B, int k3, int world,
+                      int rank, uint64_t* se, uint64_t* nc, uint64_t* meta, hipStream_t st);
+void launch_h1x_certify(const uint64_t* red, int world, int B, int lp, int k3, const uint64_t* D, const int* Dc, int L,
+                        const uint64_t* S, const int* Sc, int L_s, int* fail, int* nfail, hipStream_t st);
 
 // ---- prep.hip ----------------------------------------------------------------
 // Derive the stored vectors of rows [0,n) of `raw` (fp32 [n x dim]):
@@ -291,6 +297,9 @@ struct SparseRescoreArgs {
   uint64_t* out;               // [B x stride] exact keys of the candidates: slots [0, out_cnt[b]) (0 = foreign id)
   int* out_cnt;                // [B] candidates = the prefix of the list within the margin of its L-th key
   int* q_fail;                 // set when the list was cut short of the margin
+  int blocks;                  // workgroups (of 4 waves) per query; 0: 32 (a list of ~110 candidates, more when the L-th ties)
+  const uint32_t* thr_in;      // optional [B]: the integer-score threshold to apply instead of the list's own
+                               // (a shard of the candidates-first exchange applies the GLOBAL one: shardx.hip)
 };
 void launch_sparse_rescore(const SparseRescoreArgs& a, hipStream_t st);
 // out[b] = the parts' lists of query b packed into one run (stride pt * lout), out_cnt[b] = its length

@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void k_sparse_rescore(SparseRescoreArgs a) {
   if (a.q_flag[b] == 0) {
     n = a.cnt[b];
     n = n < a.stride ? n : a.stride;
-    if (n >= a.limit) thr = spr_thr((uint32_t)(list[a.limit - 1] >> 32), a.q_margin[b]);
+    if (a.thr_in) thr = a.thr_in[b];
+    else if (n >= a.limit) thr = spr_thr((uint32_t)(list[a.limit - 1] >> 32), a.q_margin[b]);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the list is sorted by integer score: the candidates are a prefix
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void k_sparse_rescore(SparseRescoreArgs a) {
   const bool pre = T <= 64;
   const int32_t qi_lane = (pre && lane < T) ? a.q_idx[qb + lane] : -1;
   const float qw_lane = (pre && lane < T) ? a.q_val[qb + lane] : 0.0f;
-  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += SPR_BLOCKS * 4) {   // wave-uniform
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int)gridDim.x * 4) {   // wave-uniform
     const uint64_t ck = list[i];
     if ((uint32_t)(ck >> 32) < thr) break;      // sorted: nothing further passes
     uint64_t k = 0ull;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void k_sparse_rescore(SparseRescoreArgs a) {
 }
 void launch_sparse_rescore(const SparseRescoreArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.stride <= 0) return;
-  hipLaunchKernelGGL(k_sparse_rescore, dim3(SPR_BLOCKS, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_sparse_rescore, dim3(a.blocks > 0 ? a.blocks : SPR_BLOCKS, a.B), dim3(256), 0, st, a);
   HX_HIP(hipGetLastError());
 }
 

@@ -239,9 +239,11 @@ class H1Pipeline:
         self.cf = cf_ok if candidates_first is None else bool(candidates_first and cf_ok)
         if self.cf:
             try:
-                self.k1, self.k2, self.lp, self.ks = sh.ops.h1_plan(dense_limit, sparse_limit, max(sh.world, 1))
+                self.k1, self.k2, self.lp, self.k3, self.lout = sh.ops.h1_plan(dense_limit, sparse_limit, max(sh.world, 1))
                 cap = 8192 // max(sh.world, 1) // 32 * 32       # world x k keys are merged in one 8192-key buffer
-                self.k1max, self.k2max = min(max(self.lp, self.k1), cap), min(max(self.ks, self.k2), cap)
+                L32 = (sparse_limit + 31) // 32 * 32
+                self.k1max = min(max((self.lp + 31) // 32 * 32, self.k1), cap)
+                self.k2max, self.k3max = min(max(L32, self.k2), cap), min(max(L32, self.k3), cap, 256)
                 sh.sync_sparse_scale()
             except Exception:          # limits the plan does not take: the per-shard exchange serves them
                 self.cf = False
@@ -269,11 +271,12 @@ class H1Pipeline:
     def _exchange_candidates_first(self, nom, inputs, B):
         sh = self.sh
         dl, sl, limit, rrf_k, rank_base = self.args
-        k1, k2, lp, ks = self._cfk
-        g = nom if sh.world == 1 else sh.gather_raw(nom.view(1, -1)).view(-1)       # [world * B * (k1 + k2 + 2)]
-        res = sh.local.h1_rescore_async(*inputs, g, sh.world, dl, sl, k1, k2, lp, ks)
+        k1, k2, lp, k3 = self._cfk
+        pub = nom[:B * (k1 + k2 + 2)]                                               # (the rest is this rank's own)
+        g = pub if sh.world == 1 else sh.gather_raw(pub.view(1, -1)).view(-1)       # [world * B * (k1 + k2 + 2)]
+        res = sh.local.h1_rescore_async(*inputs, nom, g, sh.world, sh.rank, dl, sl, k1, k2, lp, k3)
         sh.reduce_sum(res)
-        keys, cnt, nfail = sh.ops.h1_finish(res, sh.world, B, lp, ks, dl, sl, limit, rrf_k, rank_base)
+        keys, cnt, nfail = sh.ops.h1_finish(res, sh.world, B, lp, k3, dl, sl, limit, rrf_k, rank_base)
         return (keys, cnt), self._pinned(nfail.to(torch.int64))
 
     def submit(self, q, q_indptr, q_idx, q_val):
@@ -284,8 +287,8 @@ class H1Pipeline:
         B = q.shape[0]
         cf = self.cf
         if cf:
-            self._cfk = (self.k1, self.k2, self.lp, self.ks)
-            mine = sh.local.h1_nominate_async(q, q_indptr, q_idx, q_val, dl, sl, self.k1, self.k2)
+            self._cfk = (self.k1, self.k2, self.lp, self.k3)
+            mine = sh.local.h1_nominate_async(q, q_indptr, q_idx, q_val, dl, sl, self.k1, self.k2, self.lout)
         else:
             mine = sh.local.h1_local_async(q, q_indptr, q_idx, q_val, dl, sl)      # enqueued; no host round trip
         done = None
@@ -326,9 +329,10 @@ class H1Pipeline:
             out[1].copy_(c)
             self.redone += 1
             if self.cf:             # (the same decision on every rank: the flag words are the same)
-                if self.k1 >= self.k1max and self.k2 >= self.k2max:
+                if self.k1 >= self.k1max and self.k2 >= self.k2max and self.k3 >= self.k3max:
                     self.cf = False     # full-length lists were still not enough: the per-shard exchange from here on
                 self.k1, self.k2 = min(2 * self.k1, self.k1max), min(2 * self.k2, self.k2max)
+                self.k3 = min(2 * self.k3, self.k3max)
 
     def wait(self):
         while self.pending:

@@ -277,32 +277,39 @@ class HxIndex:
         """The largest document weight of ANY shard: one scale for the integer BM25 scores of all shards."""
         check(_lib.lib().hx_set_sparse_wmax(self._h, float(wmax)))
 
-    def h1_nominate_async(self, q, q_indptr, q_idx, q_val, dense_limit: int, sparse_limit: int, k1: int, k2: int):
-        """This shard's nominations, flat [B * (k1 + k2 + 2)] (hx_h1_nominate_async)."""
+    def h1_nominate_async(self, q, q_indptr, q_idx, q_val, dense_limit: int, sparse_limit: int, k1: int, k2: int,
+                          lout: Optional[int] = None):
+        """This shard's nominations (hx_h1_nominate_async): flat int64, the first B * (k1 + k2 + 2) words are what the
+        shards exchange, the B * (lout + 1) words behind them stay with the batch on this rank (h1_rescore_async)."""
         q = _need_cuda(q, torch.float32, "q")
         q_indptr = _need_cuda(q_indptr, torch.int64, "q_indptr")
         q_idx = _need_cuda(q_idx, torch.int32, "q_idx")
         q_val = _need_cuda(q_val, torch.float32, "q_val")
         B = q.shape[0]
-        nom = torch.empty((B * (k1 + k2 + 2),), dtype=torch.int64, device=q.device)
+        if lout is None:
+            lout = h1_plan(dense_limit, sparse_limit, 1)[4]
+        nom = torch.empty((B * (k1 + k2 + 2) + B * (lout + 1),), dtype=torch.int64, device=q.device)
         check(_lib.lib().hx_h1_nominate_async(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, dense_limit,
                                               sparse_limit, k1, k2, _ptr(nom), _stream()))
         return nom
 
-    def h1_rescore_async(self, q, q_indptr, q_idx, q_val, gathered: torch.Tensor, world: int, dense_limit: int,
-                         sparse_limit: int, k1: int, k2: int, lp: int, ks: int):
-        """Exact scores of this shard's rows among the global candidates, flat [B * (lp + ks + 5)] (hx_h1_rescore_async)."""
+    def h1_rescore_async(self, q, q_indptr, q_idx, q_val, nom: torch.Tensor, gathered: torch.Tensor, world: int, rank: int,
+                         dense_limit: int, sparse_limit: int, k1: int, k2: int, lp: int, k3: int):
+        """Exact scores of this shard's rows among the global candidates, flat [B * (lp + world * k3 + world + 4)]
+        (hx_h1_rescore_async).  `nom`: this rank's own h1_nominate_async result; `gathered`: every rank's public part."""
         q = _need_cuda(q, torch.float32, "q")
         q_indptr = _need_cuda(q_indptr, torch.int64, "q_indptr")
         q_idx = _need_cuda(q_idx, torch.int32, "q_idx")
         q_val = _need_cuda(q_val, torch.float32, "q_val")
         gathered = _need_cuda(gathered, torch.int64, "gathered")
+        nom = _need_cuda(nom, torch.int64, "nom")
         B = q.shape[0]
         if gathered.numel() != world * B * (k1 + k2 + 2):
             raise HxError("gathered nominations have the wrong size")
-        res = torch.empty((B * (lp + ks + 5),), dtype=torch.int64, device=q.device)
-        check(_lib.lib().hx_h1_rescore_async(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, _ptr(gathered),
-                                             world, dense_limit, sparse_limit, k1, k2, lp, ks, _ptr(res), _stream()))
+        res = torch.empty((B * (lp + world * k3 + world + 4),), dtype=torch.int64, device=q.device)
+        check(_lib.lib().hx_h1_rescore_async(self._h, _ptr(q), _ptr(q_indptr), _ptr(q_idx), _ptr(q_val), B, _ptr(nom),
+                                             _ptr(gathered), world, rank, dense_limit, sparse_limit, k1, k2, lp, k3,
+                                             _ptr(res), _stream()))
         return res
 
     def rescore(self, q: torch.Tensor, cand_keys: torch.Tensor, cand_counts: Optional[torch.Tensor],
@@ -372,24 +379,24 @@ def h1_fuse(gathered: torch.Tensor, world: int, dense_limit: int, sparse_limit: 
 
 
 def h1_plan(dense_limit: int, sparse_limit: int, world: int):
-    """(k1, k2, lp, ks) of the candidates-first exchange for `world` shards (hx_h1_plan)."""
-    v = [C.c_int32() for _ in range(4)]
+    """(k1, k2, lp, k3, lout) of the candidates-first exchange for `world` shards (hx_h1_plan)."""
+    v = [C.c_int32() for _ in range(5)]
     check(_lib.lib().hx_h1_plan(dense_limit, sparse_limit, world, *[C.byref(x) for x in v]))
     return tuple(int(x.value) for x in v)
 
 
-def h1_finish(reduced: torch.Tensor, world: int, B: int, lp: int, ks: int, dense_limit: int, sparse_limit: int, limit: int = 10,
-              k: float = 2.0, rank_base: int = 0, nfail: Optional[torch.Tensor] = None):
-    """reduced: the all-reduced (integer sum over the `world` ranks) result of h1_rescore_async.  Returns (keys [B, limit], counts [B], nfail [1]):
-    nfail = queries whose lists are not final (hx_h1_finish adds to it)."""
+def h1_finish(reduced: torch.Tensor, world: int, B: int, lp: int, k3: int, dense_limit: int, sparse_limit: int,
+              limit: int = 10, k: float = 2.0, rank_base: int = 0, nfail: Optional[torch.Tensor] = None):
+    """reduced: the all-reduced (integer sum over the `world` ranks) result of h1_rescore_async.  Returns (keys [B, limit],
+    counts [B], nfail [1]): nfail = queries whose lists are not final (hx_h1_finish adds to it)."""
     dev = reduced.device
     reduced = reduced.contiguous()
     keys = torch.empty((B, limit), dtype=torch.int64, device=dev)
     cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     if nfail is None:
         nfail = torch.zeros((1,), dtype=torch.int32, device=dev)
-    check(_lib.lib().hx_h1_finish(dev.index or 0, _ptr(reduced), world, B, lp, ks, dense_limit, sparse_limit, limit, k, rank_base,
-                                  _ptr(keys), _ptr(cnt), _ptr(nfail), _stream()))
+    check(_lib.lib().hx_h1_finish(dev.index or 0, _ptr(reduced), world, B, lp, k3, dense_limit, sparse_limit, limit, k,
+                                  rank_base, _ptr(keys), _ptr(cnt), _ptr(nfail), _stream()))
     return keys, cnt, nfail
 
 

@@ -485,14 +485,16 @@ def test_two_shards_one_gpu_merge_equals_unsharded(eng, torch_mod, synth_tables)
         s.close()
 
 
-def _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, limit, k1, k2, lp, ks):
-    """The candidates-first H1 exchange by hand on one GPU: nominate on every shard, the all-gather = cat, rescore on
-    every shard, the integer-sum all-reduce = sum, finish.  Returns (keys, counts, failed queries)."""
+def _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, limit, k1, k2, lp, k3, lout):
+    """The candidates-first H1 exchange by hand on one GPU: nominate on every shard, the all-gather = cat of the public
+    parts, rescore on every shard, the integer-sum all-reduce = sum, finish.  Returns (keys, counts, failed queries)."""
     W, B = len(shards), Qd.shape[0]
-    g = torch_mod.cat([s.h1_nominate_async(Qd, *tq, dl, sl, k1, k2) for s in shards])
-    res = [s.h1_rescore_async(Qd, *tq, g, W, dl, sl, k1, k2, lp, ks) for s in shards]
+    noms = [s.h1_nominate_async(Qd, *tq, dl, sl, k1, k2, lout) for s in shards]
+    pub = B * (k1 + k2 + 2)
+    g = torch_mod.cat([x[:pub] for x in noms])
+    res = [s.h1_rescore_async(Qd, *tq, noms[r], g, W, r, dl, sl, k1, k2, lp, k3) for r, s in enumerate(shards)]
     red = torch_mod.stack(res).sum(dim=0)
-    k, c, nf = eng.h1_finish(red, W, B, lp, ks, dl, sl, limit)
+    k, c, nf = eng.h1_finish(red, W, B, lp, k3, dl, sl, limit)
     return k, c, int(nf.item())
 
 
@@ -545,9 +547,9 @@ def test_candidates_first_exchange_equals_one_index(eng, torch_mod, synth_tables
     qsi, qsv = qsi[keep], qsv[keep]
     qip = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
     tq = (torch_mod.from_numpy(qip).cuda(), torch_mod.from_numpy(qsi.astype(np.int32)).cuda(), torch_mod.from_numpy(qsv).cuda())
-    k1, k2, lp, ks = eng.h1_plan(dl, sl, world)
-    assert k1 < lp and k1 % 32 == 0 and k2 % 32 == 0 and lp >= dl and ks >= sl
-    k, c, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, ks)
+    k1, k2, lp, k3, lout = eng.h1_plan(dl, sl, world)
+    assert k1 < lp and k1 % 32 == 0 and k2 % 32 == 0 and k3 % 32 == 0 and lp >= dl
+    k, c, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, k3, lout)
     assert nf == 0
     s_, i_, c_ = unpack_np(eng, k, c)
     hp = eng.make_params(dict(P_MCP, dense_limit=dl, sparse_limit=sl, final_limit=10), mode=eng.HX_MODE_H1)
@@ -558,7 +560,7 @@ def test_candidates_first_exchange_equals_one_index(eng, torch_mod, synth_tables
         assert_list_equal(s_[b], i_[b], c_[b], es, ei, f"candidates first vs oracle b={b}")
     # shards that scale their integer scores differently must be caught, not merged
     shards[0].set_sparse_wmax(2.0 * wmax)
-    _, _, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, ks)
+    _, _, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, k3, lout)
     assert nf == B
     one.close()
     for s in shards:
@@ -574,7 +576,7 @@ def test_candidates_first_flags_what_it_cannot_serve(eng, torch_mod, synth_table
     per = n // world
     X = O.synth_dense(81, 0, n, dim)
     Q = O.synth_dense(82, 0, B, dim)
-    k1, k2, lp, ks = eng.h1_plan(dl, sl, world)
+    k1, k2, lp, k3, lout = eng.h1_plan(dl, sl, world)
     # (a) queries 0-3: lp near-copies of the query, all in shard 2
     for b in range(4):                               # (graded: the exact scores spread far wider than the certificate radius)
         X[2 * per + 500 * b:2 * per + 500 * b + lp] = Q[b] + (0.05 + 0.002 * np.arange(lp, dtype=np.float32))[:, None] * \
@@ -598,7 +600,7 @@ def test_candidates_first_flags_what_it_cannot_serve(eng, torch_mod, synth_table
     for s in shards:
         s.set_sparse_wmax(wmax)
     Qd = torch_mod.from_numpy(Q).cuda()
-    k, c, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, ks)
+    k, c, nf = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, k1, k2, lp, k3, lout)
     assert nf >= 8, nf                               # (a) and (b) at least
     # the flags per query are not part of the ABI's output; the lists of every query OUTSIDE the planted ones must be final
     hp = eng.make_params(dict(P_MCP, dense_limit=dl, sparse_limit=sl, final_limit=10), mode=eng.HX_MODE_H1)
@@ -607,7 +609,7 @@ def test_candidates_first_flags_what_it_cannot_serve(eng, torch_mod, synth_table
     for b in list(range(4, 8)) + list(range(12, B)):
         assert_list_equal(s_[b], i_[b], c_[b], s1[b, :c1[b]], i1[b, :c1[b]], f"b={b}")
     # with full-length lists (k1 = lp) nothing is cut: only the certificate failures of (b) remain
-    _, _, nf_full = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, lp - lp % 32 + 32, k2, lp, ks)
+    _, _, nf_full = _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, 10, lp - lp % 32 + 32, k2, lp, k3, lout)
     assert 4 <= nf_full < nf, (nf_full, nf)
     one.close()
     for s in shards:
