@@ -318,11 +318,18 @@ def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, hp_h1=No
                       achieved_tflops=p16["flops"] / p16["ms"] / 1e9 if p16["ms"] else None, peak_tflops=PEAK_FP16_TFLOPS,
                       frac=p16["flops"] / p16["ms"] / 1e9 / PEAK_FP16_TFLOPS if p16["ms"] else None))
     runs = []
+    L10 = 10
+    flag = torch.zeros(1, dtype=torch.int32, device=Q.device)   # the stages' failure counts (hx_*_async): read once, below
     for b in (1, 8, 32):
         q = Q[:b].contiguous()
-        for name, fn, key in (("int8 candidate scan + exact fp32 re-score (the dense stage)", lambda: ix.search_dense(q, 10), "scan_cand8"),
-                              ("fp16 candidate scan + exact fp32 re-score", lambda: ix.search_dense(q, 10), "scan_f16"),
-                              ("int8 scan of the 'quantized' vector (exact integer scores)", lambda: ix.search_i8(q, 10), "scan_i8")):
+        # candidates re-scored per query (engine.hip: cand8_lprime / geometry): their fp32 rows are algorithmic bytes too
+        for name, fn, key, ncand in (
+                ("int8 candidate scan + exact fp32 re-score (the dense stage)", lambda: ix.search_dense(q, L10, flag=flag),
+                 "scan_cand8", max(9 * L10 // 2, L10 + 288)),
+                ("fp16 candidate scan + exact fp32 re-score", lambda: ix.search_dense(q, L10, flag=flag), "scan_f16",
+                 L10 + max(32, L10 // 2)),
+                ("int8 scan of the 'quantized' vector (exact integer scores)", lambda: ix.search_i8(q, L10, flag=flag),
+                 "scan_i8", 0)):
             ix.set_dense_candidates("f16" if key == "scan_f16" else "i8")
             fn()
             torch.cuda.synchronize()
@@ -333,14 +340,20 @@ def secondary(eng, synth, torch, ix, wl, tabs, Q, sp_q, local, hp_tree, hp_h1=No
             ix.profile(False)
             if p["ms"] > 0:
                 gbs = p["bytes"] / p["ms"] / 1e6
-                runs.append(dict(batch=b, stage=name, ms_per_pass=dt * 1e3, scan_ms_per_pass=p["ms"] / 6,   # 1 + 5 calls
-                                 scan_gbs=gbs, frac_of_hbm_peak=gbs / PEAK_HBM_GBS, queries_per_sec=b / dt))
+                pass_bytes = p["bytes"] / 6 + b * ncand * wl["dim"] * 4          # (1 + 5 calls were profiled)
+                runs.append(dict(batch=b, stage=name, ms_per_pass=dt * 1e3, scan_ms_per_pass=p["ms"] / 6,
+                                 scan_gbs=gbs, frac_of_hbm_peak=gbs / PEAK_HBM_GBS,
+                                 pass_frac_of_hbm_peak=pass_bytes / dt / 1e9 / PEAK_HBM_GBS, queries_per_sec=b / dt))
+    flagged = int(flag.item())
     ix.set_dense_candidates("i8")
     out["dense_knn_small_batch"] = dict(
-        what=f"dense kNN top-10 over the same {wl['rows']} x {wl['dim']} corpus, B queries per pass: algorithmic bytes "
-             "(rows * row_bytes + B * row_bytes of the copy that is scanned: 1 B per element for the int8 copies, 2 B "
-             "for fp16; SURVEY 8(d)) / HIP-event time of the scan launches; north-star target >= 0.70",
-        peak_gbs=PEAK_HBM_GBS, runs=runs)
+        what=f"dense kNN top-10 over the same {wl['rows']} x {wl['dim']} corpus, B queries per pass.  frac_of_hbm_peak: "
+             "algorithmic bytes of the scanned copy (rows * row_bytes + B * row_bytes: 1 B per element for the int8 copies, "
+             "2 B for fp16; SURVEY 8(d)) / HIP-event time of the scan launches.  pass_frac_of_hbm_peak: the same bytes plus "
+             "the re-scored candidates' fp32 rows / WALL time of the pass (prep, compactions, re-score, certificate "
+             "included; no host round trip: the stages' flags go to one device word, read once behind all passes -- "
+             "hx_search_*_async).  North-star target >= 0.70",
+        peak_gbs=PEAK_HBM_GBS, runs=runs, queries_not_final_in_any_pass=flagged)
     # BASELINE config 2 on an index of its own (1M x 384, dense only, B = 256), checked against the C oracle
     c2 = WORKLOADS["cfg2"]
     ix2 = eng.HxIndex(c2["dim"], (64, 128, 256), device=local)
@@ -415,9 +428,13 @@ def boundary_legs(eng, torch, ix, Q, sp_np, P, local):
     # the handler: Python lists in (what the reference's callers hold), ScoredPoint objects with payloads out
     h = H.QdrantHandler(device=local)
     col = H._Collection(ix.dim, ix.msizes, local, index=ix)
-    col.ids = _LazyRows(lambda r: f"00000000-0000-4000-8000-{r:012x}")
-    col.payloads = _LazyRows(lambda r: {"content": f"chunk {r}", "file_name": f"doc{r >> 6}.txt", "page_number": r & 63,
-                                        "chunk_number": r & 63, "document_summary": "", "context": None})
+    # ids / payloads of 10M rows would be 20 GB of Python objects: a pool of 65536 of each, looked up by row -- what the
+    # handler pays per returned row (a list index, a ScoredPoint) is what a real collection's lists cost it
+    pool_ids = [f"00000000-0000-4000-8000-{r:012x}" for r in range(65536)]
+    pool_pay = [{"content": f"chunk {r}", "file_name": f"doc{r >> 6}.txt", "page_number": r & 63, "chunk_number": r & 63,
+                 "document_summary": "", "context": None} for r in range(65536)]
+    col.ids = _LazyRows(lambda r: pool_ids[r & 65535])
+    col.payloads = _LazyRows(lambda r: pool_pay[r & 65535])
     h._collections["bench"] = col
     dense_lists = Qh.tolist()
     sparse_dicts = [{"indices": qix[qip[b]:qip[b + 1]].tolist(), "values": qv[qip[b]:qip[b + 1]].tolist()} for b in range(B)]
@@ -433,9 +450,9 @@ def boundary_legs(eng, torch, ix, Q, sp_np, P, local):
     np.asarray(dense_lists, dtype=np.float32)
     hb["list_to_ndarray_ms"] = (time.perf_counter() - t0) * 1e3
     hb["what"] = (f"B = {B} through hx_hybrid_query_host from pageable numpy buffers (abi_*), and through "
-                  "QdrantHandler.hybrid_search_batch (mode h1) with ScoredPoint + payload per returned row; payloads come from a lazy "
-                  "per-row provider (10M dicts do not fit a bench); `list_to_ndarray_ms` = the cost of packing B x 768 Python "
-                  "floats alone")
+                  "QdrantHandler.hybrid_search_batch (mode h1) with ScoredPoint + payload per returned row; ids / payloads come from "
+                  "a pool of 65536 looked up by row (10M dicts do not fit a bench); `list_to_ndarray_ms` = the cost of packing "
+                  "B x 768 Python floats alone (20-28 ns per float in CPython: the reference's call shape hands over lists)")
     h._collections.pop("bench")          # (the index belongs to the caller)
     out["host_boundary"] = hb
     return out

@@ -92,7 +92,7 @@ enum WsSlot {
   WS_F_DALL, WS_F_SALL, WS_F_D, WS_F_S, WS_F_DC, WS_F_SC,
   WS_SP_TI0, WS_SP_TI1, WS_SP_QS, WS_SP_MARGIN, WS_SP_FLAG, WS_SP_WORK, WS_SP_FAIL, WS_SP_LIST, WS_SP_LCNT,
   WS_SP_EXACT, WS_SP_ECNT, WS_SP_MM, WS_SP_FTAU, WS_SP_FOVF, WS_SP_QPARTS, WS_SP_SUM,
-  WS_ID_IN, WS_LONG_ROWS, WS_Q8S, WS_SQ, WS_EPSQ, WS_TREE_FLAG
+  WS_ID_IN, WS_LONG_ROWS, WS_Q8S, WS_SQ, WS_EPSQ, WS_TREE_FLAG, WS_DONE
 };
 
 template <typename T>
@@ -131,6 +131,7 @@ struct hx_index {
   bool cand8_off = false;             // hx_set_dense_candidates(h, 0): the copy is kept but the fp16 scan nominates
   int64_t cand8_queries = 0, cand8_failed = 0;   // queries the int8 candidate pass took / could not certify
   int64_t tree_redone = 0;            // tree batches run again the synchronous way (a deferred flag was set)
+  int done_zeroed[2] = {0, 0};        // entries of the finish kernel's per-query counters known to be zero (level 0 / retry level)
   // doc-major sparse staging (device)
   int64_t* sp_indptr = nullptr;  // [sp_rows_cap + 1]
   int32_t* sp_idx = nullptr;
@@ -507,9 +508,11 @@ static int cand8_lprime(int L) {
 }
 // lp_force > 0 (with cand8): keep exactly that many candidates -- a shard of the candidates-first H1 exchange nominates
 // its share of the global L', not L' of its own (hx_h1_nominate_async)
-static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false, int lp_force = 0) {
-  static thread_local std::map<std::tuple<int, bool, bool, bool, int>, Geometry> cache;
-  const auto key = std::make_tuple(L, approx, safe, cand8, lp_force);
+// few_queries (B <= 32): the scan is bandwidth-bound and what a launch costs is the compaction of ONE list per query
+// behind it (latency, not volume), so the growth goes as high as the buffer takes: 10M rows in 3 launches instead of 4
+static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false, int lp_force = 0, bool few_queries = false) {
+  static thread_local std::map<std::tuple<int, bool, bool, bool, int, bool>, Geometry> cache;
+  const auto key = std::make_tuple(L, approx, safe, cand8, lp_force, few_queries);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   Geometry g;
@@ -540,7 +543,8 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false, int 
     // cheaper log scatter of late round 3, dense search only: 50 / 24 / 16 / 12 -> 7.53 / 7.44 / 7.43 / 7.44 ms)
     static const int gmax8 = getenv("HX_DEBUG_GROW_MAX8") ? std::max(3, atoi(getenv("HX_DEBUG_GROW_MAX8"))) : 16;
     static const int gmax = getenv("HX_DEBUG_GROW_MAX") ? std::max(3, atoi(getenv("HX_DEBUG_GROW_MAX"))) : 64;
-    for (int gr = std::min(64, cand8 ? gmax8 : gmax); gr > 2; --gr) {
+    static const bool few_off = getenv("HX_DEBUG_NO_FEW") != nullptr;
+    for (int gr = std::min(64, (few_queries && !few_off) ? 64 : (cand8 ? gmax8 : gmax)); gr > 2; --gr) {
       const int kq = predict_rank(g.Lp, (double)gr);
       if (kq < g.Lp && 1.0 - nb_cdf(kq, 1.0 / gr, g.C - g.Lp) <= PREDICT_EPS) {
         g.grow = gr;
@@ -557,7 +561,12 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false, int 
 }
 
 // query-tile width of the scan kernel for a batch of B queries
-static int scan_bn(int B) { return B <= 32 ? 32 : (B <= 64 ? 64 : (B <= 128 ? 128 : 256)); }
+static int scan_bn(int B) {
+  // 81..128 queries go to the 256 x 256 kernel too (half its columns padding): measured on 10M x 768 int8, ms per pass,
+  // 128-wide tile / 256-wide: B = 65 2.04 / 2.13, 96 2.15 / 2.03, 128 2.28 / 2.13 (profiles/r04_mid_batch.txt)
+  static const int t128 = getenv("HX_DEBUG_BN128_MAX") ? atoi(getenv("HX_DEBUG_BN128_MAX")) : 80;
+  return B <= 32 ? 32 : (B <= 64 ? 64 : (B <= t128 ? 128 : 256));
+}
 
 struct MatrixRef {
   const float* m32;
@@ -863,7 +872,7 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
   // (level 1) like any other flagged query.  Final scores are spec_dot on the fp32 rows either way.
   const bool use8 = h->cand8 && !h->cand8_off && h->q8s && prefix == 0 && level == 0;
   if (m.m16 || use8) {
-    const Geometry g = geometry(L, true, level > 0, use8);
+    const Geometry g = geometry(L, true, level > 0, use8, 0, B <= 32);
     uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND + wo, (size_t)B * g.C * 8);
     uint64_t* cand2 = (uint64_t*)h->ws.get(WS_CAND2 + wo, (size_t)B * g.C * 8);
     int* cnt = (int*)h->ws.get(WS_CNT + wo, (size_t)B * 4);
@@ -898,11 +907,20 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     r.max_cnt = g.Lp;       // chunked_scan's last compaction keeps at most L' keys
     r.B = B;
     r.out = cand2;
-    launch_rescore_list(r, st);
-    launch_compact(cand2, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
     if (defer && flag_acc) nfail = flag_acc;
     else HX_HIP(hipMemsetAsync(nfail, 0, 4, st));
-    launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st, eps_q);
+    // re-score + top-L + certificate in one launch (select.hip: k_dense_finish) when the lists fit a wave's registers
+    unsigned int* done = (unsigned int*)h->ws.get(WS_DONE + wo, (size_t)B * 4);
+    if (h->done_zeroed[level > 0] < B) {              // the kernel leaves its counters at zero: cleared once per growth
+      HX_HIP(hipMemsetAsync(done, 0, (size_t)B * 4, st));
+      h->done_zeroed[level > 0] = B;
+    }
+    static const bool no_fuse = getenv("HX_DEBUG_NO_FINISH_FUSE") != nullptr;
+    if (no_fuse || !launch_dense_finish(r, g.Lp, L, out_keys, out_cnt, ovf, HX_EPS_F16, eps_q, fail, nfail, done, st)) {
+      launch_rescore_list(r, st);
+      launch_compact(cand2, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
+      launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st, eps_q);
+    }
     if (between) between();
     if (defer) return false;
     sel = read_failures(h, fail, nfail, B, st);
@@ -943,7 +961,7 @@ static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* o
   int8_t* q8 = (int8_t*)h->ws.get(WS_Q8 + wo, (size_t)Bpad * h->dim_pad8);
   float* rq = (float*)h->ws.get(WS_RINVQ + wo, (size_t)Bpad * 4);
   launch_prep_queries_i8(q_dev, h->dim, B, Bpad, h->dim_pad8, q8, rq, st);
-  const Geometry g = geometry(L, false, level > 0);
+  const Geometry g = geometry(L, false, level > 0, false, 0, B <= 32);
   uint64_t* cand = (uint64_t*)h->ws.get(WS_CAND + wo, (size_t)B * g.C * 8);
   int* cnt = (int*)h->ws.get(WS_CNT + wo, (size_t)B * 4);
   int* ovf = (int*)h->ws.get(WS_OVF + wo, (size_t)B * 4);

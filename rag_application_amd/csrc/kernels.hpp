@@ -106,6 +106,11 @@ struct RescoreArgs {
   int max_cnt;             // upper bound of cnt[] (0: stride): sizes the grid; slots beyond it are NOT written
 };
 void launch_rescore_list(const RescoreArgs& a, hipStream_t st);
+// exact re-score of the (<= 512) candidates of every query + top-L + the certificate of launch_certify, one launch
+// (r.out = scratch [B x stride]; done = [B] zeroed counters, left zero).  Returns false when the sizes do not fit
+// (lprime or L above 512): use launch_rescore_list + launch_compact + launch_certify.
+bool launch_dense_finish(const RescoreArgs& r, int lprime, int L, uint64_t* out_keys, int* out_cnt, const int* overflow,
+                         float eps, const float* eps_q, int* fail, int* nfail, unsigned int* done, hipStream_t st);
 
 // Exact scores of ALL rows [row_begin,row_end) for the listed queries (fallback path):
 // out[qsel[f]*stride + slot0 + (row-row_begin)] = key.

@@ -406,6 +406,9 @@ void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st, hipEvent_t
   const int64_t tiles = (n_rows + bm - 1) / bm * a.nq_tiles;
   static const bool qres_on = !getenv("HX_DEBUG_NO_QRES");      // diagnostics: the streamed query tile for every shape
   const bool qres = qres_on && bn == 32 && a.nq_tiles == 1 && a.row_bytes <= QRES_KT * 128;
+  // (Round 4, measured and dropped: the resident query tile for 64 / 128 queries too -- 48 / 96 KiB of LDS beside a
+  // three-stage ring of corpus rows leaves ONE 4-wave workgroup per CU: 2.57-3.37 ms per 10M-row pass against 1.51-1.91
+  // with two workgroups streaming both operands, profiles/r04_mid_batch.txt)
   if (kind == KIND_F16) {
     if (bn == 256) launch<KIND_F16, 256, 256, 2>(a, tiles, st);
     else if (bn == 128) launch<KIND_F16, 128, 128, 2>(a, tiles, st);

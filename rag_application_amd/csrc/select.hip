@@ -108,30 +108,20 @@ __global__ __launch_bounds__(NT) void k_compact(const uint64_t* __restrict__ key
 // is a bitonic run holding the best 64 E of both, sorted again by the last stages.  One barrier per round
 // instead of one per stage (66 at P = 2048).
 // ---------------------------------------------------------------------------------
-template <int NW, int E>
-__global__ __launch_bounds__(NW * 64) void k_compact_top(const uint64_t* __restrict__ keys, int stride,
-                                                         const int* __restrict__ in_cnt, int keep,
-                                                         uint64_t* out_keys, int out_stride, int* out_cnt,
-                                                         float* tau, int tau_rank, int chk_rank, int* kept_io,
-                                                         int* underflow) {
+// The fold itself, for a block of exactly NW waves: src[0, n) (n <= NW * 64 E) -> wave 0 holds the best 64 E keys in v,
+// sorted (index lane * E + e); returns the number of non-empty keys.  Every thread of the block must call it.
+template <int NW, int E, typename LOAD>
+__device__ __forceinline__ int compact_top_core(LOAD&& load, int n, uint64_t (&v)[E], int lane, int w) {
   constexpr int R = 64 * E;          // keys per wave
   // a wave hands its run to its partner through slot w / 2: the only earlier reader of that slot is the wave itself
   // (as the partner of wave w + 1 in the first round), so NW / 2 slots serve every round
   __shared__ uint64_t buf[NW > 1 ? (NW / 2) * R : 1];
   __shared__ int s_tot[NW];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int n = in_cnt ? in_cnt[b] : stride;
-  const int n_raw = n;
-  n = n < stride ? n : stride;
-  n = n < NW * R ? n : NW * R;
-  const uint64_t* src = keys + (int64_t)b * stride;
-  uint64_t v[E];
   int tot = 0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {   // the order inside an unsorted run is free: coalesced loads
     const int i = w * R + e * 64 + lane;
-    v[e] = i < n ? src[i] : 0ull;
+    v[e] = i < n ? load(i) : 0ull;
     tot += __popcll(__ballot(v[e] != 0ull));
   }
   if (n > w * R) w_sort<R>(v, lane);
@@ -156,6 +146,25 @@ __global__ __launch_bounds__(NW * 64) void k_compact_top(const uint64_t* __restr
 #pragma unroll
     for (int x = 0; x < NW; ++x) tot += s_tot[x];
   }
+  return tot;
+}
+
+template <int NW, int E>
+__global__ __launch_bounds__(NW * 64) void k_compact_top(const uint64_t* __restrict__ keys, int stride,
+                                                         const int* __restrict__ in_cnt, int keep,
+                                                         uint64_t* out_keys, int out_stride, int* out_cnt,
+                                                         float* tau, int tau_rank, int chk_rank, int* kept_io,
+                                                         int* underflow) {
+  constexpr int R = 64 * E;          // keys per wave
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int n = in_cnt ? in_cnt[b] : stride;
+  const int n_raw = n;
+  n = n < stride ? n : stride;
+  n = n < NW * R ? n : NW * R;
+  const uint64_t* src = keys + (int64_t)b * stride;
+  uint64_t v[E];
+  const int tot = compact_top_core<NW, E>([&](int i) { return src[i]; }, n, v, lane, w);
   uint64_t* o = out_keys + (int64_t)b * out_stride;
   const int kept = tot < keep ? tot : keep;
   for (int i = R + tid; i < out_stride; i += NW * 64) o[i] = 0ull;
@@ -318,6 +327,115 @@ void launch_rescore_list(const RescoreArgs& a, hipStream_t st) {
   const int m = (a.max_cnt > 0 && a.max_cnt < a.stride) ? a.max_cnt : a.stride;
   hipLaunchKernelGGL(k_rescore_list, dim3((m + 3) / 4, a.B), dim3(256), 0, st, a);
   HX_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------
+// the dense stage's finish in ONE launch: exact re-score of the candidates, top-L, certificate
+// ---------------------------------------------------------------------------------
+// grid (NB, B).  Every block scores its share of query b's candidates (one wave per row, as k_rescore_list) into `tmp`;
+// the block that finishes LAST for the query (a counter per query, device scope) sorts the <= 512 exact keys in one
+// wave's registers (wsort.hpp, 8 per lane), writes the top L and applies the certificate of k_certify in place.  Before:
+// k_rescore_list + k_compact_top + k_certify, three launches behind every scan -- at B <= 32 their launch gaps were a
+// tenth of the pass.
+struct FinishArgs {
+  RescoreArgs r;           // cand = the candidate keys (approximate scores, best first), cnt, stride; out = tmp [B x stride]
+  int lprime;              // candidates the approximate pass keeps when its list is full
+  int L;
+  uint64_t* out_keys;      // [B x L]
+  int* out_cnt;            // [B]
+  const int* overflow;     // [B]
+  float eps;
+  const float* eps_q;      // optional [B]
+  int* fail;               // [B]
+  int* nfail;              // += failed queries
+  unsigned int* done;      // [B] zero before the launch; left zero
+};
+template <int E>
+__global__ __launch_bounds__(256) void k_dense_finish(FinishArgs f) {
+  const RescoreArgs& a = f.r;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  int n = a.cnt ? a.cnt[b] : a.stride;
+  n = n < a.stride ? n : a.stride;
+  n = n < 512 ? n : 512;
+  uint64_t* tmp = a.out + (int64_t)b * a.stride;
+  for (int i = blockIdx.x * 4 + w; i < n; i += (int)gridDim.x * 4) {      // wave-uniform
+    const uint64_t ck = a.cand[(int64_t)b * a.stride + i];
+    uint64_t k = 0ull;
+    if (ck != 0ull) {
+      const int64_t local = (int64_t)key_id(ck) - a.id_base;
+      if (local >= 0 && local < a.n_rows) k = exact_key(a, b, local, lane);
+    }
+    if (lane == 0) __hip_atomic_store(tmp + i, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __shared__ int s_last;
+  // The keys were stored with agent scope (sc1: written through, no dirty line stays in this XCD's L2), so "visible
+  // device-wide" is "acknowledged": s_waitcnt vmcnt(0).  (A __threadfence() here is a write-back of the whole L2 per
+  // block -- 2400 of them at B = 32 cost 0.15 ms, more than the three launches this kernel replaces.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(f.done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;                               // (block-uniform)
+  // the last block of the query: top-L of the <= 512 exact keys, its four waves folding as k_compact_top<4, E>
+  uint64_t v[E];
+  const int tot = compact_top_core<4, E>(
+      [&](int i) { return __hip_atomic_load(tmp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, n, v, lane, w);
+  const int kept = tot < f.L ? tot : f.L;
+  uint64_t* o = f.out_keys + (int64_t)b * f.L;
+  for (int i = 64 * E + (int)threadIdx.x; i < f.L; i += 256) o[i] = 0ull;
+  if (w != 0) return;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = lane * E + e;
+    if (i < f.L) o[i] = i < kept ? v[e] : 0ull;
+  }
+  // the L-th exact key
+  const int kr = f.L - 1;
+  uint64_t mine = v[0];
+#pragma unroll
+  for (int e = 1; e < E; ++e) mine = (kr & (E - 1)) == e ? v[e] : mine;
+  const uint64_t kL = (uint64_t)__shfl((unsigned long long)mine, (kr / E) & 63, 64);
+  if (lane == 0) {
+    f.out_cnt[b] = kept;
+    float eps = f.eps_q ? f.eps_q[b] : f.eps;
+    bool bad = f.overflow[b] != 0;
+    const int ac = a.cnt ? a.cnt[b] : a.stride;
+    if (!bad && ac >= f.lprime) {                    // the candidate list is full: rows outside it score <= m
+      const float m = key_score(a.cand[(int64_t)b * a.stride + f.lprime - 1]);
+      if (tot < f.L) bad = true;                     // cannot happen (lprime > L distinct rows), be safe
+      else bad = !(__fadd_rn(m, eps) < key_score(kL));
+    }
+    f.fail[b] = bad ? 1 : 0;
+    if (bad) atomicAdd(f.nfail, 1);
+    f.done[b] = 0u;                                  // for the next launch
+  }
+}
+bool launch_dense_finish(const RescoreArgs& r, int lprime, int L, uint64_t* out_keys, int* out_cnt, const int* overflow,
+                         float eps, const float* eps_q, int* fail, int* nfail, unsigned int* done, hipStream_t st) {
+  if (lprime > 512 || L > 512 || L < 1 || r.stride < lprime) return false;
+  if (r.B <= 0) return true;
+  FinishArgs f{};
+  f.r = r;
+  f.lprime = lprime;
+  f.L = L;
+  f.out_keys = out_keys;
+  f.out_cnt = out_cnt;
+  f.overflow = overflow;
+  f.eps = eps;
+  f.eps_q = eps_q;
+  f.fail = fail;
+  f.nfail = nfail;
+  f.done = done;
+  // a small batch gets a wave per candidate (the chip is otherwise idle), a large one has blocks enough
+  const int nb = r.B <= 64 ? (lprime + 3) / 4 : 16;
+  // E keys per lane: the top 64 E end in wave 0 (L <= 64 E), 4 x 64 E keys fit the fold (>= 512 from E = 2)
+  if (L <= 128) hipLaunchKernelGGL(k_dense_finish<2>, dim3(nb, r.B), dim3(256), 0, st, f);
+  else if (L <= 256) hipLaunchKernelGGL(k_dense_finish<4>, dim3(nb, r.B), dim3(256), 0, st, f);
+  else hipLaunchKernelGGL(k_dense_finish<8>, dim3(nb, r.B), dim3(256), 0, st, f);
+  HX_HIP(hipGetLastError());
+  return true;
 }
 
 __global__ __launch_bounds__(256) void k_rescore_range(RangeArgs a) {

@@ -12,6 +12,7 @@ default)."""
 from __future__ import annotations
 
 import asyncio
+import itertools
 import json
 import logging
 import os
@@ -270,12 +271,16 @@ class QdrantHandler:
         q = np.asarray(dense_vectors, dtype=np.float32).reshape(len(sparse_vectors), -1)
         if q.shape[1] != col.dim:
             raise ValueError(f"query dimension {q.shape[1]} != collection dimension {col.dim}")
-        indptr, idx, val = [0], [], []
-        for sv in sparse_vectors:
-            si, vv = _sparse_parts(sv)
-            idx.extend(int(i) for i in si)
-            val.extend(float(v) for v in vv)
-            indptr.append(len(idx))
+        parts = [_sparse_parts(sv) for sv in sparse_vectors]
+        indptr = np.zeros(len(parts) + 1, np.int64)
+        np.cumsum([len(si) for si, _ in parts], out=indptr[1:])
+        nnz = int(indptr[-1])
+        # (one pass over the batch's terms, no per-element int() / float() calls: the packing of a 1024-query batch is host
+        # time the GPU waits for)
+        idx = np.fromiter(itertools.chain.from_iterable(si for si, _ in parts), dtype=np.int64, count=nnz)
+        val = np.fromiter(itertools.chain.from_iterable(vv for _, vv in parts), dtype=np.float64, count=nnz)
+        if nnz and (idx.min() < -2 ** 31 or idx.max() >= 2 ** 31):
+            raise ValueError("sparse index out of range")
         if mode not in ("tree", "h1"):
             raise ValueError("mode must be 'tree' (the reference query) or 'h1'")
         # KeyError/TypeError like the reference when search_params lacks a key / is None
@@ -289,12 +294,11 @@ class QdrantHandler:
             # So: ask the engine for the whole re-scored union and filter it here.
             _filters.matches({}, filters)                  # validates the clause names before any GPU work
             hp.final_limit = min(int(hp.dense_limit) + int(hp.rrf_limit), 2048)
-        scores, ids, counts = col.index.hybrid_query_host(
-            q, np.asarray(indptr, np.int64), np.asarray(idx, np.int32), np.asarray(val, np.float32), hp)
+        scores, ids, counts = col.index.hybrid_query_host(q, indptr, idx.astype(np.int32), val.astype(np.float32), hp)
         out = []
-        for b in range(q.shape[0]):
-            pts = [ScoredPoint(id=col.ids[int(r)], version=0, score=float(s), payload=col.payloads[int(r)])
-                   for s, r in zip(scores[b, :counts[b]], ids[b, :counts[b]])]
+        cids, cpay = col.ids, col.payloads
+        for sc, rw, n in zip(scores.tolist(), ids.tolist(), counts.tolist()):     # (python floats / ints in one go)
+            pts = [ScoredPoint(id=cids[r], version=0, score=s, payload=cpay[r]) for s, r in zip(sc[:n], rw[:n])]
             if filters:
                 pts = [p for p in pts if _filters.matches(p.payload, filters, p.id)][:final_limit]
             out.append(pts)
