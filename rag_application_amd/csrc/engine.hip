@@ -522,7 +522,7 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false, int 
   int c = next_pow2(std::max(8 * g.Lp, 1024));
   if (cand8) {
     static const int cmin = getenv("HX_DEBUG_CAND8_C") ? atoi(getenv("HX_DEBUG_CAND8_C")) : 4096;
-    static const int cmin_n = getenv("HX_DEBUG_NOM_C") ? atoi(getenv("HX_DEBUG_NOM_C")) : 2048;
+    static const int cmin_n = getenv("HX_DEBUG_NOM_C") ? atoi(getenv("HX_DEBUG_NOM_C")) : 1024;   // (8 x 1.25M rows: 1.585 ms per step at 1024, 1.605 at 2048, 1.81 at 4096)
     c = std::max(c, lp_force > 0 ? cmin_n : cmin);
   }
   g.C = safe ? CAND_CAP : std::min(c, CAND_CAP);
@@ -2084,12 +2084,12 @@ int hx_h1_plan(int32_t dense_limit, int32_t sparse_limit, int32_t world, int32_t
   HX_CHECK(k1 && k2 && lp && k3 && lout, "NULL argument");
   HX_CHECK(dense_limit >= 1 && dense_limit <= MAX_LIMIT && sparse_limit >= 1 && sparse_limit <= MAX_LIMIT, "limit out of range [1, 2048]");
   HX_CHECK(world >= 1 && world <= 64, "world out of range [1, 64]");
-  // a shard's share of a global list of n is Binomial(n, 1/world) on exchangeable rows: mean + 10 sigma (+ 8), to a
+  // a shard's share of a global list of n is Binomial(n, 1/world) on exchangeable rows: mean + 10 sigma, to a
   // multiple of 32; a topically clustered collection trips the completeness checks instead and the caller widens the
   // lists (distributed.H1Pipeline doubles them after a redone batch)
   auto share = [&](int n) {
     const double p = 1.0 / world, mean = n * p, sd = std::sqrt(n * p * (1.0 - p));
-    return (int)std::min<int64_t>(round_up((int64_t)std::ceil(mean + 10.0 * sd + 8.0), 32), round_up(n, 32));
+    return (int)std::min<int64_t>(round_up((int64_t)std::ceil(mean + 10.0 * sd), 32), round_up(n, 32));
   };
   const int cap = CAND_CAP / world / 32 * 32;       // world x k keys are merged in one 8192-key buffer
   HX_CHECK(cap >= 32, "world too large for the candidates-first exchange");
@@ -2231,7 +2231,7 @@ int hx_h1_rescore_async(hx_index* h, const float* qd, const int64_t* qip, const 
     r.max_cnt = lp;
     r.B = B;
     r.out = de;
-    launch_rescore_list(r, st);
+    launch_rescore_own(r, st);                         // (most slots of G belong to other shards)
     remap_out(h, de, (int64_t)B * lp, st);
   }
   // ---- this rank's documents at or above the GLOBAL threshold, from its own list of the nominate step: exact

@@ -106,6 +106,8 @@ struct RescoreArgs {
   int max_cnt;             // upper bound of cnt[] (0: stride): sizes the grid; slots beyond it are NOT written
 };
 void launch_rescore_list(const RescoreArgs& a, hipStream_t st);
+// as launch_rescore_list for a list that is mostly OTHER shards' rows: only this shard's slots are scored and written
+void launch_rescore_own(const RescoreArgs& a, hipStream_t st);
 // exact re-score of the (<= 512) candidates of every query + top-L + the certificate of launch_certify, one launch
 // (r.out = scratch [B x stride]; done = [B] zeroed counters, left zero).  Returns false when the sizes do not fit
 // (lprime or L above 512): use launch_rescore_list + launch_compact + launch_certify.

@@ -322,6 +322,37 @@ __global__ __launch_bounds__(256) void k_rescore_list(RescoreArgs a) {
   if (lane == 0) a.out[(int64_t)b * a.stride + i] = out;
 }
 
+// The same for a list most of whose slots belong to OTHER shards (the global candidate list of the candidates-first
+// exchange: one slot in `world` is this shard's).  A wave takes 64 slots, finds its own by one ballot and scores only
+// those -- k_rescore_list starts a wave per slot, 7 of 8 of which find a foreign id and leave.  Slots that are not this
+// shard's are NOT written (the caller zeroed `out`).
+__global__ __launch_bounds__(256) void k_rescore_own(RescoreArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int b = blockIdx.y;
+  int n = a.cnt ? a.cnt[b] : a.stride;
+  n = n < a.stride ? n : a.stride;
+  if (c0 >= n) return;
+  const int i = c0 + lane;
+  const uint64_t ck = i < n ? a.cand[(int64_t)b * a.stride + i] : 0ull;
+  const int64_t local = (int64_t)key_id(ck) - a.id_base;
+  const bool own = ck != 0ull && local >= 0 && local < a.n_rows;
+  unsigned long long m = __ballot(own);
+  while (m) {                                          // wave-uniform
+    const int l = __builtin_ctzll(m);
+    m &= m - 1ull;
+    const int64_t row = __shfl((long long)local, l, 64);
+    const uint64_t k = exact_key(a, b, row, lane);
+    if (lane == 0) a.out[(int64_t)b * a.stride + c0 + l] = k;
+  }
+}
+void launch_rescore_own(const RescoreArgs& a, hipStream_t st) {
+  if (a.B <= 0 || a.stride <= 0) return;
+  const int m = (a.max_cnt > 0 && a.max_cnt < a.stride) ? a.max_cnt : a.stride;
+  hipLaunchKernelGGL(k_rescore_own, dim3((m + 255) / 256, a.B), dim3(256), 0, st, a);
+  HX_HIP(hipGetLastError());
+}
+
 void launch_rescore_list(const RescoreArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.stride <= 0) return;
   const int m = (a.max_cnt > 0 && a.max_cnt < a.stride) ? a.max_cnt : a.stride;

@@ -127,6 +127,28 @@ def test_search_dense(small, eng, torch_mod, B, limit, prefix):
         assert_list_equal(s[b], i[b], c[b], es, ei, f"dense b={b}")
 
 
+@pytest.mark.parametrize("B", [33, 64, 65, 80, 81, 128, 129, 255])
+@pytest.mark.parametrize("cand", ["i8", "f16"])
+def test_dense_batches_between_the_tiles(eng, torch_mod, B, cand):
+    """33 <= B <= 255: the 128 x {64, 128} tiles of k_scan up to 80 queries, the 256 x 256 kernel (padding columns) from 81
+    -- both sides of every boundary, int8 and fp16 candidates, on a corpus large enough for the chunked scan (several
+    launches, thresholds in force), against the C oracle."""
+    from oracle import c_oracle as CO
+    n, dim, L = 60000, 256, 10
+    X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
+    Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
+    es, ei, ec = CO.search_dense(CO.cosine_preprocess(X), CO.cosine_preprocess(Q), L)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    ix.set_dense_candidates(cand)
+    s, i, c = unpack_np(eng, *ix.search_dense(torch_mod.from_numpy(Q).cuda(), L))
+    for b in range(B):
+        assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"B={B} {cand} b={b}")
+    st = ix.stats()
+    assert st["dense_fallback_queries"] == 0, st
+    ix.close()
+
+
 @pytest.mark.parametrize("B,limit", [(1, 10), (9, 40), (70, 300), (129, 40)])
 def test_search_i8(small, eng, torch_mod, B, limit):
     ora, ix, _ = small
