@@ -587,3 +587,61 @@ def test_sharded_handler_times_out_on_a_hanging_rank():
     out, dt = ret["search"]
     assert out == [] and dt < 10.0
     assert ret["store"][0] == "raised" and ret["store"][1] < 10.0
+
+
+def deal_fail_worker(rank, world, port, dim, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import asyncio
+    import time
+    from oracle import oracle as O
+    from rag_application_amd import sharded as SH
+    tabs = O.synth_tables()
+    h = SH.ShardedHandler(index_factory=lambda d, ms, base: GrowingShard(d, ms, base), ops=CpuOpsH1, dense_vector_size=dim,
+                          timeout=3)
+    if rank != 0:
+        real = SH.ShardedCollection._deal_arrays
+        calls = {"n": 0}
+
+        def failing(self, *a, **kw):               # the worker dies inside the deal of the SECOND batch
+            calls["n"] += 1
+            if calls["n"] == 2:
+                raise RuntimeError("worker lost inside the deal")
+            return real(self, *a, **kw)
+        SH.ShardedCollection._deal_arrays = failing
+        h.serve()                                  # must END: an out-of-step worker leaves the loop
+        ret["worker_broken"] = bool(h.broken)
+    else:
+        run = asyncio.run
+        chunks = _chunks(O, tabs, 60, dim)
+        run(h.store_document_vectors(chunks, "u"))
+        t0 = time.time()
+        try:
+            run(h.store_document_vectors(chunks, "u"))
+            ret["store"] = "stored"
+        except SH.ShardError:
+            ret["store"] = ("raised", time.time() - t0)
+        ret["front_broken"] = bool(h.broken)
+        Q = O.synth_dense(O.SEED_QUERY, 0, 1, dim)
+        t0 = time.time()
+        out = run(h.hybrid_search("u", "t", Q[0].tolist(), {"indices": [1], "values": [1.0]}, search_params=P))
+        ret["search"] = (out, time.time() - t0)
+    time.sleep(1.0)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_handler_closes_when_a_rank_fails_inside_the_deal():
+    """A rank that fails INSIDE the point-to-point deal of a batch leaves the ranks out of step (round 3: the front
+    rank kept issuing commands on the control group).  Now the store raises within the timeout, the handler is closed
+    on the front rank (`broken`), the worker leaves its serve() loop, and a later search returns [] at once instead of
+    waiting on a group nobody answers on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(deal_fail_worker, args=(2, port, 128, ret), nprocs=2, join=True)
+    assert ret["store"][0] == "raised" and ret["store"][1] < 10.0
+    assert ret["front_broken"] and ret["worker_broken"]
+    out, dt = ret["search"]
+    assert out == [] and dt < 1.0

@@ -2,6 +2,7 @@
 reference exercises, without the HTTP layer): ingest ~1k text chunks, query, and get
 a list whose elements expose .payload["content"] / ["file_name"]."""
 import asyncio
+import os
 
 import numpy as np
 import pytest
@@ -408,3 +409,38 @@ def test_sharded_handler_real_shards_two_ranks_one_gpu():
         es, ei = O.hybrid_h1(enc, Qt[b], np.asarray(i_, np.int64), np.asarray(v_, np.float32), 20, 20, 10)
         assert [t[0] for t in ret["texts"][b]] == ei.tolist(), (b, ret["texts"][b], ei)
         np.testing.assert_array_equal(np.array([t[1] for t in ret["texts"][b]], np.float32).view(np.uint32), es.view(np.uint32))
+
+
+@pytest.mark.timeout(600)
+def test_bench_starts_its_own_ranks_and_the_candidates_first_pipeline_equals_one_index():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the driver's command): bench.py starts one process per rank itself,
+    before it touches the GPU.  Two ranks share this box's one GPU (the explicit HX_DIST_BACKEND=gloo rehearsal), every
+    step starts with the C2 broadcast, the H1 batches run through distributed.H1Pipeline with the candidates-first
+    exchange over real gloo collectives, and rank 0 checks the last step's lists against ONE index over all rows, key for
+    key (HX_BENCH_VERIFY).  Also: asking for more GPUs than there are over RCCL is an error line, not a hang."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HX_DIST_BACKEND="gloo", HX_BENCH_PIPE="1", HX_BENCH_VERIFY="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "400000", "--steps", "3",
+                        "--warmup", "1", "--no-secondary", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["batches_in_flight"] == 2
+    assert line["config"]["sharded_equals_single_index"] is True
+    assert "pipeline_fallback" not in line["config"]
+    # more ranks than GPUs over RCCL: refused with an error line and a non-zero exit code
+    import torch
+    env2 = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "HX_DIST_BACKEND"):
+        env2.pop(k, None)
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env2,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    err = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "error" in err and err["n_gpus"] == n
