@@ -52,7 +52,7 @@
 #define HX_SP_THREADS 512
 #endif
 #ifndef HX_SP_EXP
-#define HX_SP_EXP 0      // timing experiments only (wrong results): 1-3 LDS atomics removed, 4 no posting loads, 5 aligned loads, 6 no LDS traffic
+#define HX_SP_EXP 0      // timing experiments only (wrong results): 1-3 LDS atomics removed, 4 no posting loads, 5 aligned loads, 6 no LDS traffic, 7 posting loads from L2
 #endif
 
 namespace hx {
@@ -353,6 +353,9 @@ __device__ __forceinline__ uint4 sp_load2(const uint2* post, uint32_t off, uint3
 #elif HX_SP_EXP == 5    // timing experiment: 16-byte aligned loads (reads the wrong pair for odd offsets)
   return *(const uint4*)(post + ((off + i) & ~1u));
 #endif
+#if HX_SP_EXP == 7    // timing experiment: every chunk reads from the first 512 KiB of the postings (L2 hits; wrong results)
+  off &= 0xFFFFu;
+#endif
   const SpPair p = *(const SpPair*)(post + off + i);
   return make_uint4(p.x, p.y, p.z, p.w);
 }
@@ -591,6 +594,18 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
           }
         }
       };
+      // The units of the prefetched slots FIRST, unconditionally, in straight-line code: these are the uses hipcc places
+      // its counted waits in front of (vmcnt(3 SP_K - 1) .. vmcnt(2 SP_K): the loads of the next two visits stay in
+      // flight).  Round 3's order -- the dense segment's first round of loads ahead of these uses -- left a different
+      // number of loads in flight on the two paths, and hipcc waited with vmcnt(0) here in one visit of three and again
+      // behind barrier X: the whole prefetch drained.
+      uint32_t u0[SP_K], u1[SP_K];
+#pragma unroll
+      for (int k = 0; k < SP_K; ++k) {
+        const float qk = sp_lane_f(qs_lane, (int)((tpack >> (6 * k)) & 63u));
+        u0[k] = sp_units(cur.p[k].y, qk);
+        u1[k] = sp_units(cur.p[k].w, qk);
+      }
       uint32_t c0 = (uint32_t)(SP_K * SP_WAVES + wave);
       if (nch > (uint32_t)(SP_K * SP_WAVES)) {          // scalar: more chunks than the prefetched slots
         asm volatile("" ::: "memory");                  // (keeps hipcc from hoisting this onto the common path)
@@ -600,14 +615,26 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
         if (c0 < nch) load_round(c0);
       }
 #pragma unroll
-      for (int k = 0; k < SP_K; ++k)
-        sp_accumulate(cur.p[k], (mask >> (2 * k)) & 3u, sp_lane_f(qs_lane, (int)((tpack >> (6 * k)) & 63u)),
-                      (tpack >> (24 + k)) & 1u);
-      while (c0 < nch) {
+      for (int k = 0; k < SP_K; ++k) {
+        const uint32_t mk = (mask >> (2 * k)) & 3u;
+        if ((tpack >> (24 + k)) & 1u) {                 // scalar: a full chunk, no predicate
+          sp_add1(cur.p[k].x, u0[k]);
+          sp_add1(cur.p[k].z, u1[k]);
+        } else {
+          if (mk & 1u) sp_add1(cur.p[k].x, u0[k]);
+          if (mk & 2u) sp_add1(cur.p[k].z, u1[k]);
+        }
+      }
+      if (c0 < nch) {
+        while (c0 < nch) {
 #pragma unroll
-        for (int k = 0; k < SP_K; ++k) sp_accumulate(r[k], rm[k], rq[k], false);
-        c0 += SP_K * SP_WAVES;
-        if (c0 < nch) load_round(c0);
+          for (int k = 0; k < SP_K; ++k) sp_accumulate(r[k], rm[k], rq[k], false);
+          c0 += SP_K * SP_WAVES;
+          if (c0 < nch) load_round(c0);
+        }
+        // a real s_waitcnt instruction (not inline asm): hipcc's wait insertion reads it and knows that no load of this
+        // loop is in flight behind it
+        __builtin_amdgcn_s_waitcnt(0x0F70);
       }
       SP_STAMP(2)
       lds_barrier();                                    // ---- X: every posting of the segment is in
@@ -639,10 +666,13 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
 #pragma unroll
         for (int k = 0; k < SP_K; ++k) hm[k] = (mask >> (2 * k)) & 3u;
         sp_harvest_batch(cur.p, hm, lane, cand, tau, gbase);
-        while (c0 < nch) {
-          sp_harvest_batch(r, rm, lane, cand, tau, gbase);
-          c0 += SP_K * SP_WAVES;
-          if (c0 < nch) load_round(c0);
+        if (c0 < nch) {
+          while (c0 < nch) {
+            sp_harvest_batch(r, rm, lane, cand, tau, gbase);
+            c0 += SP_K * SP_WAVES;
+            if (c0 < nch) load_round(c0);
+          }
+          __builtin_amdgcn_s_waitcnt(0x0F70);          // (as behind the loop of the accumulate phase)
         }
       }
 #else
@@ -671,6 +701,10 @@ __global__ __launch_bounds__(SP_THREADS, SEG_DOCS == 65536 ? SP_THREADS / 256 : 
       SP_STAMP(4)
       lds_barrier();                                    // ---- Y: acc is all zero again
       SP_STAMP(5)
+      // the stage's registers stay live to here: handed to the dense-segment loops as destinations of THEIR loads (they
+      // were dead behind the takes), the next issue into this stage had to wait for loads of unknown age
+#pragma unroll
+      for (int k = 0; k < SP_K; ++k) asm volatile("" ::"v"(cur.p[k].x), "v"(cur.p[k].y), "v"(cur.p[k].z), "v"(cur.p[k].w));
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)nx1.nch);
   };
