@@ -36,7 +36,7 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec
 SPARSE_ARITH = "16-bit integer select pass over the inverted index + exact re-score in upstream order (fp32 running sum, ascending term id)"
 DENSE_ARITH = ("int8 MFMA candidate scan over a per-row-scaled int8 copy of the normalised rows + exact fp32 re-score of "
                "the candidates, certified per query (a query the certificate does not cover is re-run on the fp16 copy)")
-PMC_PROFILE = "r03_pmc_scan.json"   # committed rocprofv3 --pmc pass the `traffic` figure is read from
+PMC_PROFILE = "r04_pmc_scan.json"   # committed rocprofv3 --pmc pass the `traffic` figure is read from
 
 
 def parse():
@@ -626,8 +626,17 @@ def main():
     ix.finalize()
     ev_b.record()
     torch.cuda.synchronize()
-    k9_ms = ev_a.elapsed_time(ev_b)
+    k9_cold_ms = ev_a.elapsed_time(ev_b)
     t_build = time.perf_counter() - t_build
+    # ... and once more (hx_rebuild_sparse): the first build of a fresh process also pays for 32 GB of temporary device
+    # allocations -- 45 ms or 1.2 s on two boxes of the pool for the same kernels; the second is the kernels' time
+    k9_ms = k9_cold_ms
+    if rank == 0 and world == 1 and mode == "h1" and not args.no_secondary:
+        ev_a.record()
+        ix.rebuild_sparse()
+        ev_b.record()
+        torch.cuda.synchronize()
+        k9_ms = ev_a.elapsed_time(ev_b)
 
     # ---- queries, resident in HBM ------------------------------------------------------
     Q = eng.synth_queries_dense(dim, 0, B, synth.SEED_QUERY, device=local)
@@ -832,11 +841,13 @@ def main():
             k9_bytes = float(st_main["nnz"]) * 8.0 * 2.0 * k9_passes
             side["ingest"]["index_build_1e9" if rows == WORKLOADS["cfg3"]["rows"] else "index_build"] = dict(
                 kernel="K9 build_sparse_index (spbuild.hip): term-major postings + per-(term, segment) offsets from the "
-                       "document-major CSR", postings=st_main["nnz"], ms=k9_ms, sort_passes=k9_passes,
+                       "document-major CSR", postings=st_main["nnz"], ms=k9_ms, first_build_of_the_process_ms=k9_cold_ms,
+                sort_passes=k9_passes,
                 alg_gb=k9_bytes / 1e9, gbs=k9_bytes / k9_ms / 1e6, frac_of_hbm_peak=k9_bytes / k9_ms / 1e6 / PEAK_HBM_GBS,
                 bound="hbm", peak_gbs=PEAK_HBM_GBS, chunks_per_sec=rows / (k9_ms / 1e3),
-                note="HIP events around hx_finalize on the first build of the timed index (generation of the synthetic "
-                     "corpus excluded); bytes = nnz * 8 * 2 * sort passes (SURVEY 8d)")
+                note="HIP events around the SECOND build of the timed index (hx_rebuild_sparse; generation of the synthetic "
+                     "corpus excluded; the first build also pays for its temporary allocations); bytes = nnz * 8 * 2 * sort "
+                     "passes (SURVEY 8d); the sort is rocPRIM's 8-bit onesweep over the 31-bit term ids, 4 passes")
             if mode == "h1":
                 try:
                     side.update(boundary_legs(eng, torch, ix, Q, (qip, qix, qv), P, local))

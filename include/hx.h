@@ -329,6 +329,9 @@ typedef struct hx_prof {
  * default; a query its certificate does not cover is re-run on the fp16 copy), 0 = the fp16 copy.  The lists are the
  * same either way (final scores are exact fp32): this is a measurement and test switch. */
 int hx_set_dense_candidates(hx_index* h, int32_t kind);
+/* Build the inverted index again from the stored sparse vectors (K9; hx_finalize builds it once and keeps it): a
+ * measurement aid for the index-build rate -- the first build of a process also pays for its temporary allocations. */
+int hx_rebuild_sparse(hx_index* h);
 int hx_profile(hx_index* h, int32_t enable);
 int hx_profile_read(hx_index* h, hx_prof* out);
 /* copy the derived row `row` (local) of one named vector to the host:

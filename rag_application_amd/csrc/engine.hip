@@ -1801,6 +1801,19 @@ int hx_finalize(hx_index* h) {
   HX_CATCH
 }
 
+// the inverted index again from the document-major CSR (what the first search after a bulk ingest, or hx_finalize, does
+// once): a measurement aid -- the first build of a fresh process also pays for its 32 GB of temporary allocations
+int hx_rebuild_sparse(hx_index* h) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  h->set_device();
+  HX_HIP(hipDeviceSynchronize());
+  free_sparse_index(h);
+  h->sparse_stale = true;
+  finalize(h, nullptr);
+  HX_CATCH
+}
+
 int hx_count(hx_index* h, int64_t* n_rows) {
   HX_TRY
   HX_CHECK(h && n_rows, "NULL argument");

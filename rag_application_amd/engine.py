@@ -156,6 +156,10 @@ class HxIndex:
     def finalize(self):
         check(_lib.lib().hx_finalize(self._h))
 
+    def rebuild_sparse(self):
+        """Build the inverted index again (hx_rebuild_sparse): a measurement aid."""
+        check(_lib.lib().hx_rebuild_sparse(self._h))
+
     def count(self) -> int:
         n = C.c_int64()
         check(_lib.lib().hx_count(self._h, C.byref(n)))

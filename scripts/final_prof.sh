@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-V=${1:-r03}
+V=${1:-r04}
 timeout -k 10 500 python $R/bench.py > $R/gpurun_out/bench_$V.json 2> $R/gpurun_out/bench_$V.err
 echo "bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$V -o $V -- python $R/bench.py --steps 5 --no-cpu-baseline --no-secondary > $R/gpurun_out/bench_${V}p.json 2> $R/gpurun_out/bench_${V}p.err

@@ -11,9 +11,10 @@ ix.synth_fill(N, synth.SEED_CORPUS)
 out = {"rows": N, "dim": D, "peak_gbs": 8000.0, "runs": []}
 for B in (1, 8, 32):
     Q = eng.synth_queries_dense(D, 0, B, synth.SEED_QUERY)
-    for name, fn, key in (("int8 candidate scan + exact fp32 re-score, top-10 (the dense stage)", lambda: ix.search_dense(Q, 10), "scan_cand8"),
-                          ("fp16 candidate scan + exact fp32 re-score, top-10", lambda: ix.search_dense(Q, 10), "scan_f16"),
-                          ("int8 scan of the 'quantized' vector (exact), top-10", lambda: ix.search_i8(Q, 10), "scan_i8")):
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")     # the stages' failure counts (hx_*_async), read once per run
+    for name, fn, key in (("int8 candidate scan + exact fp32 re-score, top-10 (the dense stage)", lambda: ix.search_dense(Q, 10, flag=flag), "scan_cand8"),
+                          ("fp16 candidate scan + exact fp32 re-score, top-10", lambda: ix.search_dense(Q, 10, flag=flag), "scan_f16"),
+                          ("int8 scan of the 'quantized' vector (exact), top-10", lambda: ix.search_i8(Q, 10, flag=flag), "scan_i8")):
         ix.set_dense_candidates("f16" if key == "scan_f16" else "i8")
         fn(); fn(); torch.cuda.synchronize()
         ix.profile(True); ix.profile_read()
@@ -22,7 +23,10 @@ for B in (1, 8, 32):
         torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
         p = ix.profile_read()[key]; ix.profile(False)
         gbs = p["bytes"] / p["ms"] / 1e6
+        ncand = {"scan_cand8": 298, "scan_f16": 42, "scan_i8": 0}[key]      # candidates re-scored per query at L = 10
         out["runs"].append({"batch": B, "stage": name, "total_ms": round(ms, 3), "scan_ms": round(p["ms"] / 5, 3),
                             "scan_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / 8000.0, 3),
+                            "pass_frac_of_hbm_peak": round((p["bytes"] / 5 + B * ncand * D * 4) / ms / 1e6 / 8000.0, 3),
+                            "flagged": int(flag.item()),
                             "queries_per_s": round(B / ms * 1e3, 1)})
 print(json.dumps(out))

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in declared_functions():
         assert getattr(cdll, name) is not None, name
     cdll.hx_abi_version.restype = C.c_int
-    assert cdll.hx_abi_version() == 2
+    assert cdll.hx_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header(tmp_path):
