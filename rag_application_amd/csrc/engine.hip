@@ -916,7 +916,9 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
       h->done_zeroed[level > 0] = B;
     }
     static const bool no_fuse = getenv("HX_DEBUG_NO_FINISH_FUSE") != nullptr;
-    if (no_fuse || !launch_dense_finish(r, g.Lp, L, out_keys, out_cnt, ovf, HX_EPS_F16, eps_q, fail, nfail, done, st)) {
+    // (a small batch only: at B = 1024 the three kernels take 0.74 ms of a dense search against 0.83 through the fused one
+    // -- a wave per candidate over 113 blocks per query beats the last block's fold, and three launches are nothing there)
+    if (no_fuse || B > 64 || !launch_dense_finish(r, g.Lp, L, out_keys, out_cnt, ovf, HX_EPS_F16, eps_q, fail, nfail, done, st)) {
       launch_rescore_list(r, st);
       launch_compact(cand2, g.C, cnt, B, L, 0, out_keys, L, out_cnt, nullptr, g.Lp, st);
       launch_certify(cand, g.C, cnt, g.Lp, out_keys, L, out_cnt, L, ovf, HX_EPS_F16, B, fail, nfail, st, eps_q);

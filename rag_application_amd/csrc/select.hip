@@ -1,6 +1,7 @@
 // Candidate-list kernels: exact re-scoring (K6), top-L compaction, certificate,
 // reciprocal-rank fusion (K8), key packing.  All rankings use the 64-bit key whose
 // descending order is (score desc, id asc) -- oracle/oracle.py order_key.
+#include <cstdlib>
 #include "hx_common.hpp"
 #include "kernels.hpp"
 #include "wsort.hpp"
@@ -460,7 +461,9 @@ bool launch_dense_finish(const RescoreArgs& r, int lprime, int L, uint64_t* out_
   f.nfail = nfail;
   f.done = done;
   // a small batch gets a wave per candidate (the chip is otherwise idle), a large one has blocks enough
-  const int nb = r.B <= 64 ? (lprime + 3) / 4 : 16;
+  static const int nb_env = getenv("HX_DEBUG_FINISH_NB") ? atoi(getenv("HX_DEBUG_FINISH_NB")) : 0;
+  int nb = r.B <= 64 ? (lprime + 3) / 4 : 16;
+  if (nb_env > 0) nb = nb_env;
   // E keys per lane: the top 64 E end in wave 0 (L <= 64 E), 4 x 64 E keys fit the fold (>= 512 from E = 2)
   if (L <= 128) hipLaunchKernelGGL(k_dense_finish<2>, dim3(nb, r.B), dim3(256), 0, st, f);
   else if (L <= 256) hipLaunchKernelGGL(k_dense_finish<4>, dim3(nb, r.B), dim3(256), 0, st, f);
