@@ -408,7 +408,8 @@ void launch_scan(const ScanArgs& a, int kind, int bn, hipStream_t st, hipEvent_t
   const bool qres = qres_on && bn == 32 && a.nq_tiles == 1 && a.row_bytes <= QRES_KT * 128;
   // (Round 4, measured and dropped: the resident query tile for 64 / 128 queries too -- 48 / 96 KiB of LDS beside a
   // three-stage ring of corpus rows leaves ONE 4-wave workgroup per CU: 2.57-3.37 ms per 10M-row pass against 1.51-1.91
-  // with two workgroups streaming both operands, profiles/r04_mid_batch.txt)
+  // with two workgroups streaming both operands; a 256-row tile for 64 / 128 queries (8 waves, one workgroup per CU,
+  // three stages): 1.82-2.22 ms against 1.56-1.86 -- profiles/r04_mid_batch.txt)
   if (kind == KIND_F16) {
     if (bn == 256) launch<KIND_F16, 256, 256, 2>(a, tiles, st);
     else if (bn == 128) launch<KIND_F16, 128, 128, 2>(a, tiles, st);
