@@ -132,6 +132,11 @@ struct hx_index {
   int64_t cand8_queries = 0, cand8_failed = 0;   // queries the int8 candidate pass took / could not certify
   int64_t tree_redone = 0;            // tree batches run again the synchronous way (a deferred flag was set)
   int done_zeroed[2] = {0, 0};        // entries of the finish kernel's per-query counters known to be zero (level 0 / retry level)
+  // query-tile routing of the scans (read from the environment at hx_create: tests and diagnostics):
+  //   B <= 32: k_scan 128 x 32; <= bn64_max: k_scan 128 x 64; <= bn128_max: 128 queries per tile -- the staggered kernel's
+  //   256 x 128 form (scan8.hip, HQ) unless no_hq, then k_scan 128 x 128; above: the staggered 256 x 256 kernel
+  int bn32_max = 32, bn64_max = 32, bn128_max = 128;
+  bool no_hq = false;
   // doc-major sparse staging (device)
   int64_t* sp_indptr = nullptr;  // [sp_rows_cap + 1]
   int32_t* sp_idx = nullptr;
@@ -561,11 +566,12 @@ static Geometry geometry(int L, bool approx, bool safe, bool cand8 = false, int 
 }
 
 // query-tile width of the scan kernel for a batch of B queries
-static int scan_bn(int B) {
-  // 81..128 queries go to the 256 x 256 kernel too (half its columns padding): measured on 10M x 768 int8, ms per pass,
-  // 128-wide tile / 256-wide: B = 65 2.04 / 2.13, 96 2.15 / 2.03, 128 2.28 / 2.13 (profiles/r04_mid_batch.txt)
-  static const int t128 = getenv("HX_DEBUG_BN128_MAX") ? atoi(getenv("HX_DEBUG_BN128_MAX")) : 80;
-  return B <= 32 ? 32 : (B <= 64 ? 64 : (B <= t128 ? 128 : 256));
+// Query-tile width of the scan for a batch of B queries.  Measured on 10M x 768 int8 candidates, ms per pass / scan fraction
+// of HBM peak (profiles/r04_mid_batch.txt): the 256 x 128 form of the staggered kernel 1.53-1.59 / 0.69-0.72 over B = 48..128
+// (k_scan's 128 x 64 tile 1.71-1.77 / 0.60-0.62 at 48-64, its 128 x 128 tile 1.94-2.04 / 0.51-0.54 at 65-128, the 256-wide
+// staggered kernel 2.03-2.13 / 0.59 at 96-128); two 128-query tiles for 129..256 lose to the 256-wide form (2.46-2.93 / 1.9-2.2).
+static int scan_bn(const hx_index* h, int B) {
+  return B <= h->bn32_max ? 32 : (B <= h->bn64_max ? 64 : (B <= h->bn128_max ? 128 : 256));
 }
 
 struct MatrixRef {
@@ -660,7 +666,11 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   uint4* hitlog = nullptr;
   int* hitcnt = nullptr;
   int logcap = h->scan_logcap;
-  if (bn == 256) {   // per-wave append logs of the 256 x 256 kernel (scan8.hip)
+  // 65..128 queries: the staggered kernel in its 256-row x 128-query form (scan8.hip, HQ) -- the 128 x 128 tile of
+  // k_scan streams at half of HBM peak there, the 256-wide form of scan8 spends half its MFMAs on padding columns
+  const bool hq = bn == 128 && !h->no_hq;
+  a.half_q = hq ? 1 : 0;
+  if (bn == 256 || hq) {   // per-wave append logs of the staggered kernel (scan8.hip)
     // a wave logs about (appended per query) * B / SCAN8_WAVES entries per launch; a full log only
     // flags its queries for the retry
     // Planned per launch: the chunk [r0, r1) appends about rank * (r1 / r0 - 1) rows per query (rank = the rank whose
@@ -674,7 +684,7 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
         const int64_t p1 = plan[i - 1], nx = plan[i];
         const double growth = (double)nx / (double)p1;
         const double rank = g.predictive ? predict_rank(g.Lp, growth) : g.Lp;
-        const double waves = std::min<double>(SCAN8_WAVES, 8.0 * (double)((nx - p1 + 255) / 256) * (double)(round_up(B, 256) / 256));
+        const double waves = std::min<double>(SCAN8_WAVES, 8.0 * (double)((nx - p1 + 255) / 256) * (double)(round_up(B, bn) / bn));
         want = std::max(want, 3.0 * rank * (growth - 1.0) * (double)B / waves + 64.0);
       }
     }
@@ -859,7 +869,7 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
   }
   const int wo = 1000 * level;  // workspace slots of this level
   const MatrixRef m = pick_matrix(h, prefix);
-  const int bn = scan_bn(B);
+  const int bn = scan_bn(h, B);
   const int Bpad = (int)round_up(B, bn);
   float* qn = (float*)h->ws.get(WS_QN + wo, (size_t)B * m.dpad * 4);
   _Float16* qh = (_Float16*)h->ws.get(WS_QH + wo, (size_t)Bpad * m.dpad * 2);
@@ -958,7 +968,7 @@ static void search_i8(hx_index* h, const float* q_dev, int B, int L, uint64_t* o
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   if (h->n == 0) return zero_outputs(out_keys, out_cnt, B, L, st);
   const int wo = 1000 * level;
-  const int bn = scan_bn(B);
+  const int bn = scan_bn(h, B);
   const int Bpad = (int)round_up(B, bn);
   int8_t* q8 = (int8_t*)h->ws.get(WS_Q8 + wo, (size_t)Bpad * h->dim_pad8);
   float* rq = (float*)h->ws.get(WS_RINVQ + wo, (size_t)Bpad * 4);
@@ -1517,6 +1527,10 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
   }
   if (const char* e = getenv("HX_DENSE_CAND")) h->cand8 = strcmp(e, "f16") == 0 ? 0 : 1;   // candidate pass: i8 (default) | f16
   if (const char* e = getenv("HX_DEBUG_SP_CUTSTEP")) h->sp_cut_step = std::max(0, atoi(e));
+  if (const char* e = getenv("HX_DEBUG_BN32_MAX")) h->bn32_max = std::max(0, atoi(e));       // tests / diagnostics: scan routing
+  if (const char* e = getenv("HX_DEBUG_BN64_MAX")) h->bn64_max = std::max(0, atoi(e));
+  if (const char* e = getenv("HX_DEBUG_BN128_MAX")) h->bn128_max = std::max(32, atoi(e));
+  h->no_hq = getenv("HX_DEBUG_NO_HQ") != nullptr;
   if (const char* e = getenv("HX_DEBUG_SEG_DOCS")) {       // tests: force a segment size
     const int v = atoi(e);
     if (v == SEG_DOCS_SMALL || v == SEG_DOCS_LARGE) h->seg_docs_force = v;
@@ -2153,7 +2167,7 @@ int hx_h1_nominate_async(hx_index* h, const float* qd, const int64_t* qip, const
   if (h->n > 0) {
     HX_CHECK(h->cand8 && !h->cand8_off && h->q8s, "the candidates-first exchange needs the int8 candidate copy");
     const MatrixRef m = pick_matrix(h, 0);
-    const int bn = scan_bn(B);
+    const int bn = scan_bn(h, B);
     const int Bpad = (int)round_up(B, bn);
     float* qn = (float*)w.get(WS_QN, (size_t)B * m.dpad * 4);
     launch_prep_queries_f(qd, h->dim, B, B, m.d, m.dpad, qn, nullptr, st);

@@ -39,6 +39,8 @@ struct ScanArgs {
   // k_scan only: tau is -inf and rows_end - row_begin <= cap, so every row has its own slot
   // (row - row_begin, key 0 for a NaN score or a row past n_total) and no counter is touched: the caller presets cnt.
   int all_pass;
+  // scan8 only: the 256-row x 128-query form (65..128 queries; Q holds 128-row query tiles)
+  int half_q;
   // Scan order.  [row_begin, row_end) are LOGICAL rows: logical 256-row tile t is physical tile
   // (t * perm_mul) mod perm_n (perm_n = 0: identity).  The stride is about 0.618 of the tile count, so every chunk of
   // the geometric scan is an even sample of the whole matrix: a corpus ingested document by document is topically

@@ -73,7 +73,13 @@ constexpr int S8_MAXQ = 4096;      // queries whose thresholds fit the LDS table
 
 // TS = MFMA tile side: 32 (v_mfma_*_32x32x16_f16 / 32x32x32_i8) or 16 (16x16x32_f16 / 16x16x64_i8).
 // Same LDS image, same number of 16-byte fragment reads and of matrix-pipe cycles per phase.
-template <int KIND, int TS, int DBG>
+// HQ ("half the queries", round 4): a 256-row x 128-query tile for batches of 65..128 queries.  Same skeleton, slots and
+// barriers; a wave owns 128 rows x 32 queries (the hb = 0 quadrants only), so the B1 half-tile is never staged or read and the
+// quadrants C01 / C11 are never computed: half the matrix work and three quarters of the LDS-DMA pieces per byte of corpus --
+// at 128 queries the 256-wide form spent half its MFMAs on padding columns.  Query q sits at row (q / 32) * 32 + q % 32 of a
+// 128-row query tile (wave column wn = (q / 32) % 4).  The only schedule change: phase X stages one half-tile (A1 of T + 1),
+// so its counted wait leaves 6 pieces in flight instead of 8 (g = 4T+4, 4T+5, 4T+7).
+template <int KIND, int TS, int DBG, bool HQ = false>
 __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   constexpr int MT = 64 / TS;          // row tiles of a quadrant
   constexpr int NT = 32 / TS;          // query tiles of a quadrant
@@ -126,7 +132,9 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   const int total_T = my_items * KT;   // k-tiles of this block (launch_scan8 bounds it below 2^31)
 
   // thresholds (and int8 query scales) of every query -> LDS, +inf for the padding
-  const int Bpad = nq * 256;
+  constexpr int QT = HQ ? 128 : 256;     // queries of a query tile
+  constexpr int QW = HQ ? 32 : 64;       // ... of a wave column
+  const int Bpad = nq * QT;
   for (int q = tid; q < Bpad; q += 512) {
     float t = q < a.B ? g_tau[q] : __builtin_inff();
     if constexpr (KIND == KIND_I8) {
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       offA[h][c] = (uint32_t)((rr >> 6) * 128 + h * 64 + (rr & 63)) * (uint32_t)a.row_bytes + sl;
-      offB[h][c] = (uint32_t)((rr >> 5) * 64 + h * 32 + (rr & 31)) * (uint32_t)a.row_bytes + sl;
+      offB[h][c] = (uint32_t)((rr >> 5) * QW + h * 32 + (rr & 31)) * (uint32_t)a.row_bytes + sl;
     }
   }
   // fragment read offsets inside a half-tile: row*128 + ((ks*(8/KS) + hh) ^ swz)*16
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     const int d = __builtin_amdgcn_readfirstlane(j / nq);   // keep the cursor in scalar registers
     const int rt = ONE_TILE ? 0 : (L2_TILES ? (d & 1) * 8 + xcd : d * 8 + xcd), qt = j - d * nq;
     c.a = a.A + (int64_t)phys_tile(rt) * 256 * a.row_bytes;
-    c.q = a.Q + (int64_t)qt * 256 * a.row_bytes;
+    c.q = a.Q + (int64_t)qt * QT * a.row_bytes;
   };
   auto advance = [&](Cur& c) __attribute__((always_inline)) {
     c.koff += 128;
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
   tile_ptrs(lj, c2);
   stage(c2.a, c2.koff, offA[0], 0);
   stage(c2.q, c2.koff, offB[0], 1);
-  stage(c2.q, c2.koff, offB[1], 2);
+  if (!HQ) stage(c2.q, c2.koff, offB[1], 2);
   stage(c2.a, c2.koff, offA[1], 3);
   advance(c2);                       // T = 1
   stage(c2.a, c2.koff, offA[0], 4);
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) tau_it[hb][nt] = lds_tau[qt * 256 + wn * 64 + hb * 32 + nt * TS + r];
+      for (int nt = 0; nt < NT; ++nt) tau_it[hb][nt] = lds_tau[qt * QT + wn * QW + (HQ ? 0 : hb * 32) + nt * TS + r];
     if constexpr (KIND == KIND_I8) {
       typedef __attribute__((address_space(4))) const float CF;   // constant address space + uniform index = s_load_dword
       rxm_it = ((CF*)a.rinv_tile_max)[rt];
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     // lane owns query column r of each of the NT tiles and, per row tile, EPT rows:
     //   TS = 32: rows 8*(e>>2) + 4*hh + (e&3);  TS = 16: rows 4*hh + e   (4 consecutive per group)
     // (rt is the PHYSICAL tile here: ktile maps it once per item)
-    const int q0 = qt * 256 + wn * 64 + hb * 32 + r;
+    const int q0 = qt * QT + wn * QW + (HQ ? 0 : hb * 32) + r;
     const int64_t rowq = (int64_t)rt * 256 + wm * 128 + ha * 64 + 4 * hh;
     // (plain fmaxf / max chains: hipcc forms v_max3 itself, and -- unlike an inline-asm v_max3 --
     // gets the MFMA-result wait states its hazard recognizer inserts for instructions it knows)
@@ -566,17 +574,18 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
     }
     read_a(S0 + 0);
     read_b(S0 + 1, bA);
-    read_b(S0 + 2, bB);
+    if (!HQ) read_b(S0 + 2, bB);
     // HX_S8_LDMA 1: both half-tiles of the phase staged here (the wait then leaves 8 pieces in flight: g = 4T+4 ..
     // 4T+7); 2: B1 here, A1 between the MFMAs of the second quadrant (6 in flight: 4T+4 .. 4T+6)
+    // HQ: there is no B1 -- A1 of T + 1 alone, 6 pieces stay in flight (g = 4T+4, 4T+5, 4T+7)
     if (HX_S8_LDMA) {
       __builtin_amdgcn_sched_barrier(0);
-      stage(c1.q, c1.koff, offB[1], N0 + 2);
-      if (HX_S8_LDMA == 1) stage(c1.a, c1.koff, offA[1], N0 + 3);
+      if (!HQ) stage(c1.q, c1.koff, offB[1], N0 + 2);
+      if (HX_S8_LDMA == 1 || HQ) stage(c1.a, c1.koff, offA[1], N0 + 3);
     }
-    S8_L_END(HX_S8_LDMA == 1 ? 8 : (HX_S8_LDMA == 2 ? 6 : 4))
-    S8_QUAD(acc[0][0], bA, 0, 0, c1.q, c1.koff, offB[1], N0 + 2, HX_S8_LDMA == 0)
-    S8_QUAD(acc[0][1], bB, 0, 1, c1.a, c1.koff, offA[1], N0 + 3, HX_S8_LDMA != 1)
+    S8_L_END(HQ ? 6 : (HX_S8_LDMA == 1 ? 8 : (HX_S8_LDMA == 2 ? 6 : 4)))
+    S8_QUAD(acc[0][0], bA, 0, 0, c1.q, c1.koff, offB[1], N0 + 2, HX_S8_LDMA == 0 && !HQ)
+    if (!HQ) { S8_QUAD(acc[0][1], bB, 0, 1, c1.a, c1.koff, offA[1], N0 + 3, HX_S8_LDMA != 1) }
     if (HX_S8_FILTER_IN_M == 2 && __builtin_expect(last, 0)) {   // both quadrants behind the phase's last MFMA: the first
       filter(rt, qt, 0, 0, acc[0][0]);                           // one's results are long there, its VALU work runs under
       filter(rt, qt, 0, 1, acc[0][1]);                           // the second one's MFMAs still in the pipe
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
       stage(c2.q, c2.koff, offB[0], S0 + 1);
     }
     S8_L_END(HX_S8_LDMA ? 6 : 2)
-    S8_QUAD(acc[1][1], bB, 1, 1, c2.a, c2.koff, offA[0], S0 + 0, HX_S8_LDMA == 0)
+    if (!HQ) { S8_QUAD(acc[1][1], bB, 1, 1, c2.a, c2.koff, offA[0], S0 + 0, HX_S8_LDMA == 0) }
     S8_QUAD(acc[1][0], bA, 1, 0, c2.q, c2.koff, offB[0], S0 + 1, HX_S8_LDMA == 0)
     if (HX_S8_FILTER_IN_M == 2 && __builtin_expect(last, 0)) {
       filter(rt, qt, 1, 1, acc[1][1]);
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void k_scan8(ScanArgs a) {
                         // everything of a dense search but its scan kernels, B = 1024, L = 100: 0.857 / 0.75 / 0.747 ms at 1 / 2 / 4)
 constexpr int S8_WPL = HX_S8_WPL;
 constexpr int S8_SB = 8 / S8_WPL;
-template <int KIND, int TS>
+template <int KIND, int TS, bool HQ = false>
 __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __restrict__ hitcnt,
                                                       int logcap, int n_scan_blocks, int nq_tiles,
                                                       const float* __restrict__ tau, int64_t row_end, int64_t id_base,
@@ -679,7 +688,8 @@ __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __r
   const int tid = threadIdx.x;
   const int wn = blockIdx.x & 3;                      // query column group
   const int sb0 = (blockIdx.x >> 2) * S8_SB;          // first scan workgroup
-  const int nloc = nq_tiles * 64;                     // queries of the group: q = qt*256 + wn*64 + j
+  constexpr int QT = HQ ? 128 : 256, QW = HQ ? 32 : 64, QTS = HQ ? 7 : 8;   // (k_scan8: queries per tile / per wave column)
+  const int nloc = nq_tiles * QW;                     // queries of the group: q = qt*QT + wn*QW + j
   for (int i = tid; i < nloc; i += 1024) lcnt[i] = 0;
   __syncthreads();
   static_assert(2 * S8_SB * S8_WPL == 1024 / 64, "S8_WPL waves of the workgroup per log");
@@ -723,12 +733,12 @@ __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __r
         }
       }
     ((uint32_t*)e)[3] = mask;
-    if (mask) atomicAdd(&lcnt[(q >> 8) * 64 + (q & 63)], __builtin_popcount(mask));
+    if (mask) atomicAdd(&lcnt[(q >> QTS) * QW + (q & (QW - 1))], __builtin_popcount(mask));
   }
   __syncthreads();
   for (int i = tid; i < nloc; i += 1024) {
     const int c = lcnt[i];
-    const int q = (i >> 6) * 256 + wn * 64 + (i & 63);
+    const int q = (i / QW) * QT + wn * QW + (i & (QW - 1));
     lcnt[i] = c > 0 ? atomicAdd(cnt + q, c) : 0;   // first slot of this workgroup's range
   }
   __syncthreads();
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __r
     const int64_t row0 = (int64_t)(((uint64_t)h.z << 32) | h.y);
     float rq = 0.f;
     if constexpr (KIND == KIND_I8) rq = rinv_q[q];
-    int pos = atomicAdd(&lcnt[(q >> 8) * 64 + (q & 63)], __builtin_popcount(mask));
+    int pos = atomicAdd(&lcnt[(q >> QTS) * QW + (q & (QW - 1))], __builtin_popcount(mask));
     while (mask) {
       const int bit = __builtin_ctz(mask);
       mask &= mask - 1;
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(1024) void k_scatter_log(uint4* log, const int* __r
 }
 
 bool scan8_usable(const ScanArgs& a, int bn) {
-  return bn == 256 && a.hitlog != nullptr && a.B <= S8_MAXQ && (a.row_begin & 255) == 0 &&
+  return (bn == 256 || (bn == 128 && a.half_q)) && a.hitlog != nullptr && a.B <= S8_MAXQ && (a.row_begin & 255) == 0 &&
          a.row_bytes * 256 < (1ll << 31);
 }
 
@@ -784,14 +794,28 @@ void launch_scan8(const ScanArgs& a, int kind, hipStream_t st, hipEvent_t after_
   HX_DBG_CASE(KIND_I8, 9) HX_DBG_CASE(KIND_I8, 10) HX_DBG_CASE(KIND_I8, 11)
 #undef HX_DBG_CASE
 #endif
-  if (kind == KIND_F16)
+  if (a.half_q) {      // 256 rows x 128 queries (65..128 queries)
+    if (kind == KIND_F16)
+      hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 0, true>), dim3((unsigned)g), dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 0, true>), dim3((unsigned)g), dim3(512), 0, st, a);
+  } else if (kind == KIND_F16)
     hipLaunchKernelGGL((k_scan8<KIND_F16, HX_S8_TS, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
   else
     hipLaunchKernelGGL((k_scan8<KIND_I8, HX_S8_TS, 0>), dim3((unsigned)g), dim3(512), 0, st, a);
   HX_HIP(hipGetLastError());
   if (after_kernel) HX_HIP(hipEventRecord(after_kernel, st));     // the profile times k_scan8 alone, not its log scatter
   const unsigned sg = (unsigned)((g + S8_SB - 1) / S8_SB) * 4;
-  if (kind == KIND_F16)
+  if (a.half_q) {
+    if (kind == KIND_F16)
+      hipLaunchKernelGGL((k_scatter_log<KIND_F16, HX_S8_TS, true>), dim3(sg), dim3(1024), 0, st, a.hitlog, a.hitcnt,
+                         a.logcap, (int)g, a.nq_tiles, a.tau, a.n_total, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt,
+                         a.overflow, a.cap);
+    else
+      hipLaunchKernelGGL((k_scatter_log<KIND_I8, HX_S8_TS, true>), dim3(sg), dim3(1024), 0, st, a.hitlog, a.hitcnt,
+                         a.logcap, (int)g, a.nq_tiles, a.tau, a.n_total, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt,
+                         a.overflow, a.cap);
+  } else if (kind == KIND_F16)
     hipLaunchKernelGGL((k_scatter_log<KIND_F16, HX_S8_TS>), dim3(sg), dim3(1024), 0, st, a.hitlog, a.hitcnt, a.logcap,
                        (int)g, a.nq_tiles, a.tau, a.n_total, a.id_base, a.rinv_x, a.rinv_q, a.cand, a.cnt, a.overflow,
                        a.cap);

@@ -129,11 +129,16 @@ def test_search_dense(small, eng, torch_mod, B, limit, prefix):
 
 @pytest.mark.parametrize("B", [33, 64, 65, 80, 81, 128, 129, 255])
 @pytest.mark.parametrize("cand", ["i8", "f16"])
-def test_dense_batches_between_the_tiles(eng, torch_mod, B, cand):
-    """33 <= B <= 255: the 128 x {64, 128} tiles of k_scan up to 80 queries, the 256 x 256 kernel (padding columns) from 81
-    -- both sides of every boundary, int8 and fp16 candidates, on a corpus large enough for the chunked scan (several
-    launches, thresholds in force), against the C oracle."""
+@pytest.mark.parametrize("route", ["default", "k_scan"])
+def test_dense_batches_between_the_tiles(eng, torch_mod, monkeypatch, B, cand, route):
+    """33 <= B <= 255: by default 33..128 queries go through the 256-row x 128-query form of the staggered kernel (scan8.hip,
+    HQ), more through its 256 x 256 form; route "k_scan" forces the 128 x {64, 128} tiles of k_scan the same batches used
+    before (still the path when no log buffer is at hand).  Both sides of every boundary, int8 and fp16 candidates, on a
+    corpus large enough for the chunked scan (several launches, thresholds in force), against the C oracle."""
     from oracle import c_oracle as CO
+    if route == "k_scan":
+        monkeypatch.setenv("HX_DEBUG_BN64_MAX", "64")
+        monkeypatch.setenv("HX_DEBUG_NO_HQ", "1")
     n, dim, L = 60000, 256, 10
     X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
     Q = O.synth_dense(O.SEED_QUERY, 0, B, dim)
@@ -1090,7 +1095,8 @@ def test_scan8_underflow_retry(eng, torch_mod, monkeypatch, order):
 
 
 @pytest.mark.parametrize("B", [20, 40, 100])
-def test_small_batch_scan_staging_overflows(eng, torch_mod, monkeypatch, B):
+@pytest.mark.parametrize("route", ["k_scan", "default"])
+def test_small_batch_scan_staging_overflows(eng, torch_mod, monkeypatch, B, route):
     """k_scan (batches below 256 queries) stages a workgroup's appends in LDS and places them when its tiles are done; rows
     past the staging area go through the global counter at once, rows past a query's candidate buffer flag it.  Scanned in
     physical order (HX_DEBUG_NO_PERM) with the rows most similar to the queries LAST, every later chunk passes far more
@@ -1098,6 +1104,9 @@ def test_small_batch_scan_staging_overflows(eng, torch_mod, monkeypatch, B):
     lists are the oracle's all the same (dense through both candidate kinds, the "quantized" int8 stage)."""
     from oracle import c_oracle as CO
     monkeypatch.setenv("HX_DEBUG_NO_PERM", "1")
+    if route == "k_scan":      # the 128 x {64, 128} tiles of k_scan (since round 4 the default sends 33..128 queries to scan8's
+        monkeypatch.setenv("HX_DEBUG_BN64_MAX", "64")       # 256 x 128 form, whose appends go through per-wave logs)
+        monkeypatch.setenv("HX_DEBUG_NO_HQ", "1")
     n, dim, limit = 40000, 128, 50
     rng = np.random.default_rng(11)
     Q = O.synth_dense(72, 0, B, dim)
@@ -1114,7 +1123,7 @@ def test_small_batch_scan_staging_overflows(eng, torch_mod, monkeypatch, B):
         for b in range(B):
             assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"staging {kind} b={b}")
     st = ix.stats()
-    if B <= 40:       # (100 queries share the planted rows: fewer per query, the buffers hold)
+    if B <= 40 and route == "k_scan":       # (100 queries share the planted rows: fewer per query, the buffers hold)
         assert st["retry_queries"] > 0, "no buffer overflowed: the test does not exercise what it is for"
     ix.close()
     Xu, Qu = CO.cosine_preprocess(X), CO.cosine_preprocess(Q)
