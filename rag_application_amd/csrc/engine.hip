@@ -136,6 +136,10 @@ struct hx_index {
   //   B <= 32: k_scan 128 x 32; <= bn64_max: k_scan 128 x 64; <= bn128_max: 128 queries per tile -- the staggered kernel's
   //   256 x 128 form (scan8.hip, HQ) unless no_hq, then k_scan 128 x 128; above: the staggered 256 x 256 kernel
   int bn32_max = 32, bn64_max = 32, bn128_max = 128;
+  // second stream of the one-call H1 step: the sparse stage runs beside the dense stage's tail (hybrid_query_dev)
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap_tail = true;           // HX_DEBUG_NO_OVERLAP (diagnostics): everything on the caller's stream
   bool no_hq = false;
   // doc-major sparse staging (device)
   int64_t* sp_indptr = nullptr;  // [sp_rows_cap + 1]
@@ -859,11 +863,14 @@ static void retry_subset(hx_index* h, const float* q_dev, const std::vector<int>
 static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int L, uint64_t* out_keys,
                          int* out_cnt, hipStream_t st, int level = 0,
                          const std::function<void()>& between = std::function<void()>(), bool defer = false,
-                         int* flag_acc = nullptr) {
+                         int* flag_acc = nullptr, const std::function<void()>& after_scan = std::function<void()>()) {
+  // `after_scan` (optional): called once, right behind the candidate scan's launches and before the stage's small tail
+  // kernels (exact re-score, top-L, certificate) -- the caller forks work onto another stream there
   HX_CHECK(B > 0, "B must be positive");
   HX_CHECK(L >= 1 && L <= MAX_LIMIT, "limit out of range [1, 2048]");
   if (h->n == 0) {
     zero_outputs(out_keys, out_cnt, B, L, st);
+    if (after_scan) after_scan();
     if (between) between();
     return false;
   }
@@ -902,6 +909,7 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
       chunked_scan(h, KIND_F16, (const uint8_t*)m.m16, (const uint8_t*)qh, (int64_t)m.dpad * 2, B, bn, g,
                    cand, cnt, ovf, tau, nullptr, st);
     }
+    if (after_scan) after_scan();
     RescoreArgs r{};
     r.kind = KIND_F32;
     r.M = m.m32;
@@ -947,6 +955,7 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
   } else {
     sel.resize((size_t)B);
     std::iota(sel.begin(), sel.end(), 0);
+    if (after_scan) after_scan();
     if (between) between();
     if (defer) {                         // no fp16 copy to scan: every query needs the exact path
       launch_fill_i32(flag_acc ? flag_acc : nfail, 1, B, st);
@@ -1378,10 +1387,30 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
       rrf(h, D, p->dense_limit, Dc, S, p->sparse_limit, Sc, B, rk, p->rrf_rank_base, p->final_limit, out_keys,
           out_cnt, st, w);
     };
+    // Round 4: the sparse stage runs on a second stream BESIDE the dense stage's tail.  Behind the last scan launch the
+    // dense stage is ~0.5 ms of small kernels (log scatter, two compactions, the exact re-score of 450 candidates per
+    // query -- a bandwidth-bound gather -- the certificate), none of which needs LDS; the sparse select pass holds every
+    // CU's LDS but is bound by its barriers, not by issue slots or bandwidth (section 10.2): the two co-reside.  (Beside
+    // the SCAN it does not pay: both kernels want a CU's whole LDS -- round 2, scripts/overlap_probe.py.)
+    bool forked = false;
+    auto fork = [&]() {
+      if (!h->overlap_tail) return;
+      if (!h->st2) {
+        HX_HIP(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+        HX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+      }
+      HX_HIP(hipEventRecord(h->ev_fork, st));           // (the scan has read the query batch; the sparse stage only
+      HX_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0)); //  needs what the caller's stream had produced by here)
+      sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, h->st2);
+      HX_HIP(hipEventRecord(h->ev_join, h->st2));
+      forked = true;
+    };
     const bool patched = search_dense(h, qd, B, 0, p->dense_limit, D, Dc, st, 0, [&]() {
-      sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
+      if (forked) HX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+      else sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
       fuse();
-    });
+    }, false, nullptr, fork);
     const bool sp_patched = sparse_resolve(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
     if (patched || sp_patched) fuse();
     return;
@@ -1531,6 +1560,7 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
   if (const char* e = getenv("HX_DEBUG_BN64_MAX")) h->bn64_max = std::max(0, atoi(e));
   if (const char* e = getenv("HX_DEBUG_BN128_MAX")) h->bn128_max = std::max(32, atoi(e));
   h->no_hq = getenv("HX_DEBUG_NO_HQ") != nullptr;
+  h->overlap_tail = getenv("HX_DEBUG_NO_OVERLAP") == nullptr;
   if (const char* e = getenv("HX_DEBUG_SEG_DOCS")) {       // tests: force a segment size
     const int v = atoi(e);
     if (v == SEG_DOCS_SMALL || v == SEG_DOCS_LARGE) h->seg_docs_force = v;
@@ -1557,6 +1587,9 @@ int hx_destroy(hx_index* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->pin) (void)hipHostFree(h->pin);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->st2) (void)hipStreamDestroy(h->st2);
   if (h->ids.dev) (void)hipFree(h->ids.dev);
   h->ws.release();
   delete h;
