@@ -309,6 +309,12 @@ typedef struct hx_stats {
   int64_t cand8_uncertified_queries;
   double  cand8_row_error_max;      /* largest ||x - scale * x8||_2 of any stored row: what the certificate is built from */
   int64_t tree_batches_redone;      /* HX_MODE_TREE batches whose deferred flag word was set: run again stage by stage */
+  /* ABI 3: the two speculative paths switch themselves off on a collection they keep failing on (rows the int8 grid
+   * resolves badly make the certificate's radius large for EVERY query; a flagged query costs the whole batch twice):
+   * 1 once more than 1 query in 20 of a 4096-query window was uncertified (the fp16 copy nominates from then on),
+   * 1 once 4 of 16 consecutive tree batches were redone (the tree reads its stages' flags one by one from then on). */
+  int64_t cand8_switched_off;
+  int64_t tree_deferral_switched_off;
 } hx_stats;
 int hx_get_stats(hx_index* h, hx_stats* out);
 /* HIP-event profile of the hot kernels, measured on the stream they run on.

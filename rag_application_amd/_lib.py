@@ -39,7 +39,9 @@ class HxStats(C.Structure):
         "bytes_dense_f16", "bytes_i8", "bytes_prefix", "bytes_sparse",
         "dense_fallback_queries", "i8_fallback_queries", "retry_queries", "sparse_fallback_queries",
         "bytes_i8_cand", "cand8_queries", "cand8_uncertified_queries")] + [("cand8_row_error_max", C.c_double),
-                                                                              ("tree_batches_redone", C.c_int64)]
+                                                                              ("tree_batches_redone", C.c_int64),
+                                                                              ("cand8_switched_off", C.c_int64),
+                                                                              ("tree_deferral_switched_off", C.c_int64)]
 
 
 class HxProf(C.Structure):

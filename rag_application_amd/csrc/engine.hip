@@ -131,6 +131,11 @@ struct hx_index {
   bool cand8_off = false;             // hx_set_dense_candidates(h, 0): the copy is kept but the fp16 scan nominates
   int64_t cand8_queries = 0, cand8_failed = 0;   // queries the int8 candidate pass took / could not certify
   int64_t tree_redone = 0;            // tree batches run again the synchronous way (a deferred flag was set)
+  // Adaptive guards of the two speculative paths (hx_stats): windows of recent outcomes
+  int64_t c8_win_q = 0, c8_win_f = 0; // queries / uncertified queries of the current window of the int8 candidate pass
+  bool cand8_auto_off = false;        // ... switched off by the guard (hx_set_dense_candidates(h, 1) switches it on again)
+  int tree_win_n = 0, tree_win_redone = 0;
+  bool tree_spec_off = false;
   int done_zeroed[2] = {0, 0};        // entries of the finish kernel's per-query counters known to be zero (level 0 / retry level)
   // query-tile routing of the scans (read from the environment at hx_create: tests and diagnostics):
   //   B <= 32: k_scan 128 x 32; <= bn64_max: k_scan 128 x 64; <= bn128_max: 128 queries per tile -- the staggered kernel's
@@ -944,7 +949,20 @@ static bool search_dense(hx_index* h, const float* q_dev, int B, int prefix, int
     if (between) between();
     if (defer) return false;
     sel = read_failures(h, fail, nfail, B, st);
-    if (use8) h->cand8_failed += (int64_t)sel.size();
+    if (use8) {
+      h->cand8_failed += (int64_t)sel.size();
+      // the guard: a collection whose rows the int8 grid resolves badly (one bad row widens the radius for every query)
+      // would pay an fp16 scan on top of the int8 one for query after query
+      h->c8_win_q += B;
+      h->c8_win_f += (int64_t)sel.size();
+      if (h->c8_win_q >= 4096) {
+        if (h->c8_win_f * 20 > h->c8_win_q) {
+          h->cand8_off = true;
+          h->cand8_auto_off = true;
+        }
+        h->c8_win_q = h->c8_win_f = 0;
+      }
+    }
     if (!sel.empty() && level == 0) {
       retry_subset(h, q_dev, sel, L, out_keys, out_cnt, st, level,
                    [&](const float* qs, int ns, uint64_t* ks, int* cs) {
@@ -1422,7 +1440,7 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
   // idle each time (146 us of a 12.2 ms step).
   static const bool no_spec = getenv("HX_DEBUG_TREE_SYNC") != nullptr;
   int* tflag = nullptr;
-  if (!no_spec && !tree_sync) {
+  if (!no_spec && !tree_sync && !h->tree_spec_off) {
     tflag = (int*)w.get(WS_TREE_FLAG, 4);
     HX_HIP(hipMemsetAsync(tflag, 0, 4, st));
   }
@@ -1487,7 +1505,13 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     if (h->sp_base.n_segments || h->sp_tail.n_segments)
       HX_HIP(hipMemcpyAsync(pin + 1, w.get(WS_SP_SUM, 8), 8, hipMemcpyDeviceToHost, st));
     HX_HIP(hipStreamSynchronize(st));
-    if (pin[0] | pin[1] | pin[2]) {      // some list is not final: the batch again, every stage resolving its own flags
+    const bool redo = (pin[0] | pin[1] | pin[2]) != 0;
+    // the guard: 4 redone batches within a window of 16 and the tree stops speculating on this collection
+    h->tree_win_n += 1;
+    h->tree_win_redone += redo ? 1 : 0;
+    if (h->tree_win_redone >= 4) h->tree_spec_off = true;
+    if (h->tree_win_n >= 16) h->tree_win_n = h->tree_win_redone = 0;
+    if (redo) {      // some list is not final: the batch again, every stage resolving its own flags
       h->tree_redone += 1;
       hybrid_query_dev(h, qd, qip, qix, qv, B, p, out_keys, out_cnt, st, true);
     }
@@ -2457,6 +2481,8 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   }
   out->cand8_row_error_max = (double)emax;
   out->tree_batches_redone = h->tree_redone;
+  out->cand8_switched_off = h->cand8_auto_off ? 1 : 0;
+  out->tree_deferral_switched_off = h->tree_spec_off ? 1 : 0;
   HX_CATCH
 }
 
@@ -2481,6 +2507,10 @@ int hx_set_dense_candidates(hx_index* h, int32_t kind) {
     h->cand8 = 1;
   }
   h->cand8_off = kind == 0;
+  if (kind == 1) {                  // an explicit request also resets the guard
+    h->cand8_auto_off = false;
+    h->c8_win_q = h->c8_win_f = 0;
+  }
   HX_CATCH
 }
 

@@ -1602,6 +1602,38 @@ def test_int8_candidates_fall_back_when_the_certificate_cannot_hold(eng, torch_m
     ix.close()
 
 
+def test_int8_candidate_pass_switches_itself_off_on_rows_it_cannot_resolve(eng, torch_mod):
+    """The guard of the speculative candidate pass: on a collection whose rows the int8 grid resolves badly (one dominant
+    component per row: the largest row error widens the certificate's radius for EVERY query) query after query would pay an
+    fp16 scan on top of the int8 one.  After a 4096-query window with more than one uncertified query in twenty the fp16
+    copy nominates (stats.cand8_switched_off); the lists are exact before and after; an explicit
+    hx_set_dense_candidates(h, 1) switches the pass on again."""
+    from oracle import c_oracle as CO
+    n, dim, B, L = 12000, 256, 512, 10
+    rng = np.random.default_rng(7)
+    X = O.synth_dense(141, 0, n, dim)
+    X[np.arange(n), rng.integers(0, dim, n)] = 40.0
+    Q = O.synth_dense(142, 0, B, dim)
+    Q[:200] = X[:200] + 0.05 * O.synth_dense(143, 0, 200, dim)
+    es, ei, ec = CO.search_dense(CO.cosine_preprocess(X), CO.cosine_preprocess(Q), L)
+    ix = eng.HxIndex(dim, ())
+    ix.add(X)
+    Qd = torch_mod.from_numpy(Q).cuda()
+    for rnd in range(9):                                # 8 batches fill the window
+        s, i, c = unpack_np(eng, *ix.search_dense(Qd, L))
+        if rnd in (0, 8):
+            for b in range(B):
+                assert_list_equal(s[b], i[b], c[b], es[b, :ec[b]], ei[b, :ec[b]], f"round {rnd} b={b}")
+    st = ix.stats()
+    assert st["cand8_uncertified_queries"] * 20 > 4096, st     # the premise: the certificate fails often here
+    assert st["cand8_switched_off"] == 1 and st["cand8_queries"] == 8 * B, st
+    ix.set_dense_candidates("i8")
+    ix.search_dense(Qd, L)
+    st = ix.stats()
+    assert st["cand8_switched_off"] == 0 and st["cand8_queries"] == 9 * B, st
+    ix.close()
+
+
 def test_int8_candidate_copy_survives_save_load_and_truncate(eng, torch_mod, tmp_path):
     """The candidate copy is derived data: hx_load rebuilds it from the stored rows (same lists, same error bound),
     hx_truncate keeps a valid bound."""
