@@ -1,5 +1,6 @@
-"""Diagnostic: per-rank step time of the row-sharded H1 path at N-GPU shard size, with the exchange
-replaced by a local stand-in (the lists repeated `world` times), i.e. everything but the wire."""
+"""Diagnostic: per-rank step time of the row-sharded H1 path at N-GPU shard size through the PER-SHARD exchange (rounds 2-3),
+with the exchange replaced by a local stand-in (the lists repeated `world` times), i.e. everything but the wire.
+The candidates-first exchange of round 4 is measured by scripts/shard_cf.py (real shards)."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from rag_application_amd import engine as eng, synth
@@ -33,7 +34,9 @@ print("sharded path, no wire       ms", round(timeit(lambda: sh.hybrid_h1(Q, qip
 # flags verified two batches later -- what bench.py runs at N > 1
 from rag_application_amd.distributed import H1Pipeline
 sh.gather_raw = lambda keys: keys.contiguous().repeat(world, 1)
-pipe = H1Pipeline(sh, 100, 100, 10)
+# (this stand-in REPEATS rank 0's lists for the other ranks: fine for the per-shard exchange, meaningless for the
+# candidates-first one, whose ranks must own disjoint rows -- scripts/shard_cf.py builds real shards for that)
+pipe = H1Pipeline(sh, 100, 100, 10, candidates_first=False)
 def piped(n=10):
     for _ in range(n): pipe.submit(Q, qip, qix, qv)
     pipe.wait()
