@@ -311,13 +311,13 @@ class H1Pipeline:
             out, host = self._exchange_candidates_first(mine, (q, q_indptr, q_idx, q_val), B)
         else:
             out, host = self._exchange_and_fuse(mine, B)
-        self.pending.append((done, host, (q, q_indptr, q_idx, q_val), out))
+        self.pending.append((done, host, (q, q_indptr, q_idx, q_val), out, self._cfk if cf else None))
         while len(self.pending) > self.depth:
             self._verify(self.pending.pop(0))
         return out
 
     def _verify(self, entry):
-        done, host, inputs, out = entry
+        done, host, inputs, out, shares = entry
         if done is not None:
             done.synchronize()
         if bool((host != 0).any()):        # the same words on every rank: all ranks redo the batch together
@@ -328,7 +328,9 @@ class H1Pipeline:
             out[0].copy_(k)
             out[1].copy_(c)
             self.redone += 1
-            if self.cf:             # (the same decision on every rank: the flag words are the same)
+            # (the same decision on every rank: the flag words are the same.)  Only a batch that went out with the shares
+            # in force NOW says anything about them: batches verified late had the narrower ones of before
+            if self.cf and shares is not None and shares[:2] + shares[3:] == (self.k1, self.k2, self.k3):
                 if self.k1 >= self.k1max and self.k2 >= self.k2max and self.k3 >= self.k3max:
                     self.cf = False     # full-length lists were still not enough: the per-shard exchange from here on
                 self.k1, self.k2 = min(2 * self.k1, self.k1max), min(2 * self.k2, self.k2max)
