@@ -145,6 +145,10 @@ struct hx_index {
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap_tail = true;           // HX_DEBUG_NO_OVERLAP (diagnostics): everything on the caller's stream
+  bool beside = false;                // a stage of this call runs on the second stream while the dense scans run
+  int scan_oversub = 4;               // ScanArgs.oversub of those scans (HX_DEBUG_SCAN_OVERSUB)
+  int fork_early_max = 1 << 30;       // batches of at most this many queries start the sparse stage beside the dense SCAN
+                                      // (HX_DEBUG_FORK_EARLY_MAX=0: beside the stage's tail only, as round 4 began)
   bool no_hq = false;
   // doc-major sparse staging (device)
   int64_t* sp_indptr = nullptr;  // [sp_rows_cap + 1]
@@ -679,6 +683,7 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   // k_scan streams at half of HBM peak there, the 256-wide form of scan8 spends half its MFMAs on padding columns
   const bool hq = bn == 128 && !h->no_hq;
   a.half_q = hq ? 1 : 0;
+  a.oversub = h->beside ? h->scan_oversub : 0;
   if (bn == 256 || hq) {   // per-wave append logs of the staggered kernel (scan8.hip)
     // a wave logs about (appended per query) * B / SCAN8_WAVES entries per launch; a full log only
     // flags its queries for the retry
@@ -1374,6 +1379,22 @@ static void rrf(hx_index* h, const uint64_t* a, int as, const int* ac, const uin
                  as + bs, st);
 }
 
+// The second stream of an index (the sparse stage beside the dense one) and its two events, made on first use.
+// HX_DEBUG_ST2_PRIO=1: the stream gets the device's highest priority (its few, large workgroups are placed first).
+static void ensure_side_stream(hx_index* h) {
+  if (h->st2) return;
+  static const bool hi = getenv("HX_DEBUG_ST2_PRIO") != nullptr && atoi(getenv("HX_DEBUG_ST2_PRIO")) != 0;
+  if (hi) {
+    int least = 0, greatest = 0;
+    HX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HX_HIP(hipStreamCreateWithPriority(&h->st2, hipStreamNonBlocking, greatest));
+  } else {
+    HX_HIP(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+  }
+  HX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  HX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+}
+
 static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, const int32_t* qix,
                              const float* qv, int B, const hx_params* p, uint64_t* out_keys, int* out_cnt,
                              hipStream_t st, bool tree_sync = false) {
@@ -1413,22 +1434,32 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     bool forked = false;
     auto fork = [&]() {
       if (!h->overlap_tail) return;
-      if (!h->st2) {
-        HX_HIP(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
-        HX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-      }
+      ensure_side_stream(h);
       HX_HIP(hipEventRecord(h->ev_fork, st));           // (the scan has read the query batch; the sparse stage only
       HX_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0)); //  needs what the caller's stream had produced by here)
       sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, h->st2);
       HX_HIP(hipEventRecord(h->ev_join, h->st2));
       forked = true;
     };
+    // ... and, measured late in round 4 (scripts/h1_small_batch.py, profiles/r04_h1_small_batch.txt): started beside the
+    // SCAN the step is shorter still at every batch size -- 2-32 queries 1.76-1.99 -> 1.56-1.77 ms, 1024 queries 9.58 -> 9.32
+    // (the two kernels cannot share a CU, but each fills the other's ragged ends; round 2's probe predates both kernels)
+    std::function<void()> after_scan = fork;
+    if (B <= h->fork_early_max) {
+      fork();
+      after_scan = std::function<void()>();
+    }
+    struct Beside {                     // (reset on every way out of the stage, exceptions included)
+      hx_index* h;
+      ~Beside() { h->beside = false; }
+    } beside_guard{h};
+    h->beside = forked;
     const bool patched = search_dense(h, qd, B, 0, p->dense_limit, D, Dc, st, 0, [&]() {
       if (forked) HX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
       else sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
       fuse();
-    }, false, nullptr, fork);
+    }, false, nullptr, after_scan);
+    h->beside = false;
     const bool sp_patched = sparse_resolve(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
     if (patched || sp_patched) fuse();
     return;
@@ -1452,6 +1483,26 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
   const int lim[3] = {p->matryoshka_64_limit, p->matryoshka_128_limit, p->matryoshka_256_limit};
   uint64_t* A = keys(WS_T_A, p->dense_limit);
   int* Ac = cnts(WS_T_ACNT);
+  // --- sparse (:347-354), speculative tree: enqueued FIRST, on the second stream, beside the two whole-collection dense
+  // scans (as in H1 above); joined in front of the RRF
+  uint64_t* S = keys(WS_T_B, p->sparse_limit);
+  int* Sc = cnts(WS_T_BCNT);
+  bool sp_forked = false;
+  if (tflag && h->overlap_tail && B <= h->fork_early_max) {
+    ensure_side_stream(h);
+    HX_HIP(hipEventRecord(h->ev_fork, st));
+    HX_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+    sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, h->st2);
+    h->sp_sum_pending = false;          // its summary is read with the tree's flag word below
+    h->sp_sum_fetched = false;
+    HX_HIP(hipEventRecord(h->ev_join, h->st2));
+    sp_forked = true;
+  }
+  struct Beside {
+    hx_index* h;
+    ~Beside() { h->beside = false; }
+  } beside_guard{h};
+  h->beside = sp_forked;
   if (h->n_pre == 0) {
     dense_stage(0, p->dense_limit, A, Ac);
   } else {
@@ -1480,9 +1531,10 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
   int* Dqc = cnts(WS_T_DCNT);
   rescore(h, qd, B, 0, Qc, p->quantized_limit, Qcc, p->dense_limit, Dq, Dqc, st);
   // --- sparse (:347-354)
-  uint64_t* S = keys(WS_T_B, p->sparse_limit);
-  int* Sc = cnts(WS_T_BCNT);
-  if (tflag) {
+  h->beside = false;
+  if (sp_forked) {
+    HX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+  } else if (tflag) {
     sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
     h->sp_sum_pending = false;          // its summary is read with the tree's flag word below
     h->sp_sum_fetched = false;
@@ -1585,6 +1637,8 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
   if (const char* e = getenv("HX_DEBUG_BN128_MAX")) h->bn128_max = std::max(32, atoi(e));
   h->no_hq = getenv("HX_DEBUG_NO_HQ") != nullptr;
   h->overlap_tail = getenv("HX_DEBUG_NO_OVERLAP") == nullptr;
+  if (const char* e = getenv("HX_DEBUG_FORK_EARLY_MAX")) h->fork_early_max = atoi(e);
+  if (const char* e = getenv("HX_DEBUG_SCAN_OVERSUB")) h->scan_oversub = atoi(e);
   if (const char* e = getenv("HX_DEBUG_SEG_DOCS")) {       // tests: force a segment size
     const int v = atoi(e);
     if (v == SEG_DOCS_SMALL || v == SEG_DOCS_LARGE) h->seg_docs_force = v;
@@ -2216,6 +2270,30 @@ int hx_h1_nominate_async(hx_index* h, const float* qd, const int64_t* qip, const
   h->set_device();
   hipStream_t st = (hipStream_t)stream;
   Workspace& w = h->ws;
+  // ---- sparse: the shard's integer-score list (the select pass only; ids stay internal: only the scores travel, the
+  // list itself is consumed by this rank's own rescore step) -- on the second stream, beside the dense scan
+  bool forked = false;
+  hipStream_t sst = st;
+  // OFF by default: alone the call is shorter with it (1.34 -> 1.27 ms at 1.25M rows, B = 1024), but in H1Pipeline the
+  // re-score + exchange of the previous batch already run beside it on the pipeline's side stream, and a third stream in
+  // the mix made the pipelined step LONGER (1.49 -> 1.55 ms; profiles/r04_h1_small_batch.txt)
+  static const bool nom_fork = getenv("HX_DEBUG_NOM_FORK") != nullptr && atoi(getenv("HX_DEBUG_NOM_FORK")) != 0;
+  if (h->overlap_tail && nom_fork && h->n > 0) {
+    ensure_side_stream(h);
+    HX_HIP(hipEventRecord(h->ev_fork, st));
+    HX_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+    sst = h->st2;
+    forked = true;
+  }
+  struct Beside {
+    hx_index* h;
+    ~Beside() { h->beside = false; }
+  } beside_guard{h};
+  h->beside = forked;
+  const SparseLists sl = sparse_select_lists(h, qip, qix, qv, B, sparse_limit, sst);
+  h->sp_sum_pending = false;                         // nobody will call sparse_resolve for this batch
+  h->sp_sum_fetched = false;
+  if (forked) HX_HIP(hipEventRecord(h->ev_join, h->st2));
   // ---- dense: the shard's best k1 rows by the int8 candidate score (no exact score here)
   uint64_t* cand = nullptr;
   int *cnt = nullptr, *ovf = nullptr;
@@ -2243,11 +2321,8 @@ int hx_h1_nominate_async(hx_index* h, const float* qd, const int64_t* qip, const
     h->cand8_queries += B;
     remap_out(h, cand, (int64_t)B * g.C, st);        // (identity for a shard filled in one block: skipped)
   }
-  // ---- sparse: the shard's integer-score list (the select pass only; ids stay internal: only the scores travel, the
-  // list itself is consumed by this rank's own rescore step)
-  const SparseLists sl = sparse_select_lists(h, qip, qix, qv, B, sparse_limit, st);
-  h->sp_sum_pending = false;                         // nobody will call sparse_resolve for this batch
-  h->sp_sum_fetched = false;
+  h->beside = false;
+  if (forked) HX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
   HX_CHECK(!sl.list || sl.lout == lout, "sparse list stride");
   launch_h1x_pack(cand, cstride, cnt, ovf, eq, h->n <= k1 ? 1 : 0, k1, sl.list, sl.lout, sl.lcnt, sl.flag, sl.fail, k2,
                   lout, std::max(h->sp_wmax, h->sp_wmax_shared), B, nom_dev, st);

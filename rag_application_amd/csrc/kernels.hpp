@@ -41,6 +41,10 @@ struct ScanArgs {
   int all_pass;
   // scan8 only: the 256-row x 128-query form (65..128 queries; Q holds 128-row query tiles)
   int half_q;
+  int oversub;             // k_scan only: k > 1 = k x the resident grid (less 32 workgroups), each with 1 / k of the static share --
+                           // for a scan that runs BESIDE another stream's kernels: its two workgroups per CU take the whole LDS, so
+                           // a workgroup of the other stream in the way at launch leaves a scan workgroup waiting for a whole
+                           // round of its own kernel (measured: 1.2 -> 2.2 ms); queued shares are placed as others retire
   // Scan order.  [row_begin, row_end) are LOGICAL rows: logical 256-row tile t is physical tile
   // (t * perm_mul) mod perm_n (perm_n = 0: identity).  The stride is about 0.618 of the tile count, so every chunk of
   // the geometric scan is an even sample of the whole matrix: a corpus ingested document by document is topically

@@ -392,7 +392,9 @@ __global__ __launch_bounds__(BM * 2, 2) void k_scan(ScanArgs a) {
 template <int KIND, int BM, int BN, int NSTAGE, bool QRES = false>
 static void launch(const ScanArgs& a, int64_t tiles, hipStream_t st) {
   constexpr int per_cu = BM == 256 ? 1 : 2;
-  int64_t g = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+  int64_t cap = 256 * per_cu;
+  if (a.oversub > 1 && BM != 256) cap = cap * a.oversub - 32;   // (kernels.hpp: ScanArgs.oversub)
+  int64_t g = tiles < cap ? tiles : cap;
   g = (g + 7) / 8 * 8;  // whole XCD groups; blocks without items exit at once
   hipLaunchKernelGGL((k_scan<KIND, BM, BN, NSTAGE, QRES>), dim3((unsigned)g), dim3(BM * 2), 0, st, a);
 }
