@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=64,
                     help="queries of the timed batch brute-forced on the host over the WHOLE corpus")
     ap.add_argument("--no-secondary", action="store_true", help="skip tree mode / cfg2 / small-batch side measurements")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip the extra K steps that time the kernels with nothing beside them (`roofline.alone`): profiler runs, "
+                         "whose per-kernel averages should hold the timed region's launches only")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="host threads of the CPU baseline (0 = host cores / GPUs of the host: the box share of one GPU)")
     return ap.parse_args()
@@ -726,6 +729,23 @@ def main():
     dt = time.perf_counter() - t0
     prof = ix.profile_read()
     ix.profile(False)
+    # The timed step runs its sparse stage on a second stream BESIDE the dense scans: a launch's duration above is what the
+    # kernel took while it shared the chip.  The same K steps once more with every stage on one stream (hx_set_stream_overlap)
+    # give each kernel's duration alone -- reported beside the in-situ figures as `roofline.alone`, never as `value`.
+    alone = None
+    if world == 1 and mode == "h1" and not args.no_alone:
+        ix.set_stream_overlap(False)
+        step()
+        torch.cuda.synchronize()
+        ix.profile(True)
+        ix.profile_read()
+        t0a = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        alone = dict(dt=time.perf_counter() - t0a, prof=ix.profile_read())
+        ix.profile(False)
+        ix.set_stream_overlap(True)
     # Rehearsal aid (HX_BENCH_VERIFY=1, N > 1, small --rows): rank 0 also builds the UNSHARDED corpus and
     # checks the last step's lists against it, key for key.  Never part of the timed region.
     verified = None
@@ -811,6 +831,19 @@ def main():
                     alg_gb_per_launch=sc["bytes"] / sc["launches"] / 1e9,
                     other_bound_frac=(gbs / PEAK_HBM_GBS) if mfma_bound else (tf / peak_mfma),
                     sparse_ms_per_step=prof["sparse"]["ms"] / max(args.steps, 1))
+        if alone is not None:
+            asc = alone["prof"]["scan_cand8"] if use8 else alone["prof"]["scan_f16"]
+            asp = alone["prof"]["sparse"]
+            if asc["launches"] and asc["ms"] > 0:
+                atf, agb = asc["flops"] / asc["ms"] / 1e9, asc["bytes"] / asc["ms"] / 1e6
+                roof["alone"] = dict(
+                    what="the same K steps with every stage on ONE stream (hx_set_stream_overlap(0)): the kernels' durations when "
+                         "nothing runs beside them; the timed region above runs the sparse stage beside the dense scans",
+                    ms_per_step=alone["dt"] / args.steps * 1e3, launches=asc["launches"],
+                    avg_launch_ms=asc["ms"] / asc["launches"],
+                    achieved=atf if mfma_bound else agb, frac=(atf / peak_mfma) if mfma_bound else (agb / PEAK_HBM_GBS),
+                    second_kernel=(dict(avg_launch_ms=asp["ms"] / asp["launches"], achieved=asp["bytes"] / asp["ms"] / 1e6,
+                                        frac=asp["bytes"] / asp["ms"] / 1e6 / PEAK_HBM_GBS) if asp["launches"] and asp["ms"] > 0 else None))
         sp = prof["sparse"]
         if sp["launches"] and sp["ms"] > 0:   # second kernel of the step, HBM-bound by construction
             roof["second_kernel"] = dict(kernel="k_sparse_select", bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS,

@@ -335,6 +335,10 @@ typedef struct hx_prof {
  * default; a query its certificate does not cover is re-run on the fp16 copy), 0 = the fp16 copy.  The lists are the
  * same either way (final scores are exact fp32): this is a measurement and test switch. */
 int hx_set_dense_candidates(hx_index* h, int32_t kind);
+/* Where the sparse stage of a hybrid call runs: 1 (the default) = on the index's second stream, beside the dense scans;
+ * 0 = every stage on the caller's stream, one kernel at a time -- a measurement switch: a kernel's duration (hx_profile)
+ * is its own only when nothing runs beside it.  The lists do not depend on it. */
+int hx_set_stream_overlap(hx_index* h, int32_t on);
 /* Build the inverted index again from the stored sparse vectors (K9; hx_finalize builds it once and keeps it): a
  * measurement aid for the index-build rate -- the first build of a process also pays for its temporary allocations. */
 int hx_rebuild_sparse(hx_index* h);

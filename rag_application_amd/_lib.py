@@ -99,6 +99,7 @@ _SIGS = {
     "hx_get_stats": [_P, C.POINTER(HxStats)],
     "hx_debug_row": [_P, C.c_int32, C.c_int64, _P],
     "hx_set_dense_candidates": [_P, C.c_int32],
+    "hx_set_stream_overlap": [_P, C.c_int32],
     "hx_rebuild_sparse": [_P],
     "hx_profile": [_P, C.c_int32],
     "hx_profile_read": [_P, C.POINTER(HxProf)],

@@ -683,7 +683,8 @@ static void chunked_scan(hx_index* h, int kind, const uint8_t* A, const uint8_t*
   // k_scan streams at half of HBM peak there, the 256-wide form of scan8 spends half its MFMAs on padding columns
   const bool hq = bn == 128 && !h->no_hq;
   a.half_q = hq ? 1 : 0;
-  a.oversub = h->beside ? h->scan_oversub : 0;
+  static const int os_always = getenv("HX_DEBUG_SCAN_OVERSUB_ALWAYS") ? atoi(getenv("HX_DEBUG_SCAN_OVERSUB_ALWAYS")) : 0;   // diagnostics
+  a.oversub = h->beside ? h->scan_oversub : os_always;
   if (bn == 256 || hq) {   // per-wave append logs of the staggered kernel (scan8.hip)
     // a wave logs about (appended per query) * B / SCAN8_WAVES entries per launch; a full log only
     // flags its queries for the retry
@@ -2558,6 +2559,13 @@ int hx_get_stats(hx_index* h, hx_stats* out) {
   out->tree_batches_redone = h->tree_redone;
   out->cand8_switched_off = h->cand8_auto_off ? 1 : 0;
   out->tree_deferral_switched_off = h->tree_spec_off ? 1 : 0;
+  HX_CATCH
+}
+
+int hx_set_stream_overlap(hx_index* h, int32_t on) {
+  HX_TRY
+  HX_CHECK(h, "index is NULL");
+  h->overlap_tail = on != 0;
   HX_CATCH
 }
 

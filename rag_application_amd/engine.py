@@ -174,6 +174,10 @@ class HxIndex:
         """'i8' (default) or 'f16': which copy nominates the dense stage's candidates (hx_set_dense_candidates)."""
         check(_lib.lib().hx_set_dense_candidates(self._h, {"f16": 0, "i8": 1}[kind]))
 
+    def set_stream_overlap(self, on: bool):
+        """False: every stage of a hybrid call on the caller's stream (a kernel's profiled duration is then its own)."""
+        check(_lib.lib().hx_set_stream_overlap(self._h, 1 if on else 0))
+
     def profile(self, enable: bool):
         check(_lib.lib().hx_profile(self._h, 1 if enable else 0))
 

@@ -1,5 +1,8 @@
+"""Diagnostic: H1 through hx_hybrid_query_dev, ONE call at a time (median of 20), for batches of B queries starting at query q0 of the
+bench's query stream -- with the counters of the fallback paths, to tell a scheduling effect from a fallback.  Run under
+HX_DEBUG_FORK_EARLY_MAX=0 / HX_DEBUG_SCAN_OVERSUB=k to compare placements (profiles/r04_h1_small_batch.txt)."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rag_application_amd import engine as eng, synth
 N = 10_000_000

@@ -1,3 +1,5 @@
+"""Diagnostic: a few small H1 batches, six calls each, meant to run under `rocprofv3 --kernel-trace`: the per-kernel timeline of a
+fast and a slow call of the same batch (profiles/r04_h1_small_batch.txt, item 2)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
