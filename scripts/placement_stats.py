@@ -11,7 +11,7 @@ P = dict(matryoshka_64_limit=100, matryoshka_128_limit=80, matryoshka_256_limit=
          quantized_limit=40, sparse_limit=100, final_limit=10, hnsw_ef=128)
 hp = eng.make_params(P, mode=eng.HX_MODE_H1)
 ix = eng.HxIndex(768, (64, 128, 256)); ix.reserve(N); ix.synth_fill(N, synth.SEED_CORPUS, synth.SEED_SPDOC, tabs); ix.finalize()
-for B in (1, 2, 4, 8, 16, 32):
+for B in (1, 8, 32, 128, 1024):
     for q0 in (0, 1, 5, 9, 40, 77):
         Q = eng.synth_queries_dense(768, q0, B, synth.SEED_QUERY)
         t = [torch.from_numpy(a).cuda() for a in synth.sparse_queries(synth.SEED_SPQUERY, q0, B, tabs)]
