@@ -33,6 +33,7 @@ while time.time() < t_end:
     # dense
     d = prefix or None
     es, ei, ec = CO.search_dense(CO.cosine_preprocess(X, d), CO.cosine_preprocess(Q, d), L)
+    dense_full = (ei, ec) if not prefix else None      # (kept for the one-call H1 check below)
     kind = "f16" if rng.random() < 0.25 else "i8"   # which copy nominates the candidates of the full-vector stage
     ix.set_dense_candidates(kind)
     s, i = eng.unpack(ix.search_dense(Qd, L, prefix)[0]); s, i = s.cpu().numpy(), i.cpu().numpy()
@@ -63,9 +64,26 @@ while time.time() < t_end:
         m = int(ec[b])
         assert np.array_equal(i[b, :m], ei[b, :m]) and np.array_equal(s[b, :m].view(np.uint32), es[b, :m].view(np.uint32)), \
             ("sparse", n, B, L, b)
+    # H1 through the ONE-CALL path (hx_hybrid_query_dev: its sparse stage runs on the index's second stream beside the dense
+    # scans): dense top-L (+) sparse top-L -> RRF -> top-min(L, 10), against the RRF of the C restatement's two lists
+    if dense_full is None:
+        _, dei, dec = CO.search_dense(CO.cosine_preprocess(X), CO.cosine_preprocess(Q), L)
+    else:
+        dei, dec = dense_full
+    lim = min(L, 10)
+    hp = eng.make_params(dict(matryoshka_64_limit=L, matryoshka_128_limit=L, matryoshka_256_limit=L, dense_limit=L,
+                              quantized_limit=L, sparse_limit=L, final_limit=lim, hnsw_ef=128), mode=eng.HX_MODE_H1)
+    hk, hc = ix.hybrid_query(Qd, torch.from_numpy(qip).cuda(), torch.from_numpy(qsi.astype(np.int32)).cuda(),
+                             torch.from_numpy(qsv).cuda(), hp)
+    hs, hi = eng.unpack(hk); hs, hi, hc = hs.cpu().numpy(), hi.cpu().numpy(), hc.cpu().numpy()
+    for b in range(B):
+        rs, ri = O.rrf([dei[b, :int(dec[b])], ei[b, :int(ec[b])]], limit=lim)
+        m = len(ri)
+        assert int(hc[b]) == m and np.array_equal(hi[b, :m], ri) and np.array_equal(hs[b, :m].view(np.uint32), rs.view(np.uint32)), \
+            ("h1", dim, n, B, L, b)
     st = ix.stats()
     ix.close()
-    n_cfg += 1; n_lists += 3 * B
+    n_cfg += 1; n_lists += 4 * B
     print(f"ok dim={dim} n={n} B={B} L={L} prefix={prefix} cand={kind} retries={st['retry_queries']} fallbacks={st['dense_fallback_queries']} "
           f"uncertified8={st['cand8_uncertified_queries']}/{st['cand8_queries']}", flush=True)
 print(f"fuzz parity: {n_cfg} configurations, {n_lists} lists, all bit-exact")
