@@ -147,6 +147,7 @@ struct hx_index {
   bool overlap_tail = true;           // HX_DEBUG_NO_OVERLAP (diagnostics): everything on the caller's stream
   bool beside = false;                // a stage of this call runs on the second stream while the dense scans run
   int scan_oversub = 4;               // ScanArgs.oversub of those scans (HX_DEBUG_SCAN_OVERSUB)
+  int sp_host_late_min_b = 128;       // batches from here on: the host enqueues the dense scans before the sparse stage (HX_DEBUG_SP_HOST_LATE_MIN_B)
   int fork_early_max = 1 << 30;       // batches of at most this many queries start the sparse stage beside the dense SCAN
                                       // (HX_DEBUG_FORK_EARLY_MAX=0: beside the stage's tail only, as round 4 began)
   bool no_hq = false;
@@ -1432,12 +1433,17 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     // query -- a bandwidth-bound gather -- the certificate), none of which needs LDS; the sparse select pass holds every
     // CU's LDS but is bound by its barriers, not by issue slots or bandwidth (section 10.2): the two co-reside.  (Beside
     // the SCAN it does not pay: both kernels want a CU's whole LDS -- round 2, scripts/overlap_probe.py.)
-    bool forked = false;
-    auto fork = [&]() {
+    bool forked = false, marked = false;
+    auto mark = [&]() {                                  // the point of the caller's stream the second stream starts from
       if (!h->overlap_tail) return;
       ensure_side_stream(h);
-      HX_HIP(hipEventRecord(h->ev_fork, st));           // (the scan has read the query batch; the sparse stage only
-      HX_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0)); //  needs what the caller's stream had produced by here)
+      HX_HIP(hipEventRecord(h->ev_fork, st));
+      HX_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
+      marked = true;
+    };
+    auto fork = [&]() {
+      if (!marked) mark();
+      if (!marked) return;
       sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, h->st2);
       HX_HIP(hipEventRecord(h->ev_join, h->st2));
       forked = true;
@@ -1445,16 +1451,24 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     // ... and, measured late in round 4 (scripts/h1_small_batch.py, profiles/r04_h1_small_batch.txt): started beside the
     // SCAN the step is shorter still at every batch size -- 2-32 queries 1.76-1.99 -> 1.56-1.77 ms, 1024 queries 9.58 -> 9.32
     // (the two kernels cannot share a CU, but each fills the other's ragged ends; round 2's probe predates both kernels)
+    // From 128 queries on the HOST enqueues the dense scans first all the same (sp_host_late_min_b): the second stream is tied
+    // to the START of the call (`mark`), its kernels are enqueued once the scan launches are in -- the first chunks of the scan
+    // run before the select pass holds every CU (B = 1024: 9.33-9.40 -> 9.24-9.27 ms, B = 128: 1.99 -> 1.97; below that the
+    // sparse stage is better off first: B = 8 / 32 1.57-1.77 against 1.59-1.80 ms).
     std::function<void()> after_scan = fork;
     if (B <= h->fork_early_max) {
-      fork();
-      after_scan = std::function<void()>();
+      if (B >= h->sp_host_late_min_b) {
+        mark();
+      } else {
+        fork();
+        after_scan = std::function<void()>();
+      }
     }
     struct Beside {                     // (reset on every way out of the stage, exceptions included)
       hx_index* h;
       ~Beside() { h->beside = false; }
     } beside_guard{h};
-    h->beside = forked;
+    h->beside = forked || marked;
     const bool patched = search_dense(h, qd, B, 0, p->dense_limit, D, Dc, st, 0, [&]() {
       if (forked) HX_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
       else sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, st);
@@ -1640,6 +1654,7 @@ int hx_create(int32_t dim, const int32_t* msizes, int32_t n_msizes, int32_t devi
   h->overlap_tail = getenv("HX_DEBUG_NO_OVERLAP") == nullptr;
   if (const char* e = getenv("HX_DEBUG_FORK_EARLY_MAX")) h->fork_early_max = atoi(e);
   if (const char* e = getenv("HX_DEBUG_SCAN_OVERSUB")) h->scan_oversub = atoi(e);
+  if (const char* e = getenv("HX_DEBUG_SP_HOST_LATE_MIN_B")) h->sp_host_late_min_b = atoi(e);
   if (const char* e = getenv("HX_DEBUG_SEG_DOCS")) {       // tests: force a segment size
     const int v = atoi(e);
     if (v == SEG_DOCS_SMALL || v == SEG_DOCS_LARGE) h->seg_docs_force = v;
