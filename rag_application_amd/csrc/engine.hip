@@ -1490,9 +1490,17 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     tflag = (int*)w.get(WS_TREE_FLAG, 4);
     HX_HIP(hipMemsetAsync(tflag, 0, 4, st));
   }
+  bool sp_enqueued = false;
+  std::function<void()> sparse_late;      // the sparse stage's launches, when the host enqueues them behind the first scan's
   auto dense_stage = [&](int prefix, int L, uint64_t* ok, int* oc) {
-    if (tflag) search_dense(h, qd, B, prefix, L, ok, oc, st, 0, std::function<void()>(), true, tflag);
-    else search_dense(h, qd, B, prefix, L, ok, oc, st);
+    if (tflag) {
+      std::function<void()> hook = std::move(sparse_late);
+      sparse_late = nullptr;
+      search_dense(h, qd, B, prefix, L, ok, oc, st, 0, std::function<void()>(), true, tflag, hook);
+      if (hook && !sp_enqueued) hook();   // (an empty index: no scan was launched)
+    } else {
+      search_dense(h, qd, B, prefix, L, ok, oc, st);
+    }
   };
   // --- matryoshka cascade (qdrant_handler.py:305-330)
   const int lim[3] = {p->matryoshka_64_limit, p->matryoshka_128_limit, p->matryoshka_256_limit};
@@ -1507,10 +1515,16 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
     ensure_side_stream(h);
     HX_HIP(hipEventRecord(h->ev_fork, st));
     HX_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-    sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, h->st2);
-    h->sp_sum_pending = false;          // its summary is read with the tree's flag word below
-    h->sp_sum_fetched = false;
-    HX_HIP(hipEventRecord(h->ev_join, h->st2));
+    auto enqueue = [&, S, Sc]() {
+      if (sp_enqueued) return;
+      sp_enqueued = true;
+      sparse_enqueue(h, qip, qix, qv, B, p->sparse_limit, S, Sc, h->st2);
+      h->sp_sum_pending = false;        // its summary is read with the tree's flag word below
+      h->sp_sum_fetched = false;
+      HX_HIP(hipEventRecord(h->ev_join, h->st2));
+    };
+    if (B >= h->sp_host_late_min_b) sparse_late = enqueue;   // (as in H1: the host enqueues the first scan's launches first)
+    else enqueue();
     sp_forked = true;
   }
   struct Beside {
