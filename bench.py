@@ -836,6 +836,10 @@ def main():
             asp = alone["prof"]["sparse"]
             if asc["launches"] and asc["ms"] > 0:
                 atf, agb = asc["flops"] / asc["ms"] / 1e9, asc["bytes"] / asc["ms"] / 1e6
+                roof["frac_alone"] = (atf / peak_mfma) if mfma_bound else (agb / PEAK_HBM_GBS)
+                roof["note"] = ("`achieved` / `frac` / `avg_launch_ms` are IN SITU: in the timed region k_sparse_select runs on a second "
+                                "stream beside this kernel and the two share the CUs, so a launch lasts longer than the kernel needs "
+                                "(the step is shorter for it).  `frac_alone` / `alone`: the same K steps with one kernel at a time.")
                 roof["alone"] = dict(
                     what="the same K steps with every stage on ONE stream (hx_set_stream_overlap(0)): the kernels' durations when "
                          "nothing runs beside them; the timed region above runs the sparse stage beside the dense scans",
