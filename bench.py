@@ -855,7 +855,9 @@ def main():
                                          frac=sp["bytes"] / sp["ms"] / 1e6 / PEAK_HBM_GBS,
                                          alg_gb_per_launch=sp["bytes"] / sp["launches"] / 1e9,
                                          avg_launch_ms=sp["ms"] / sp["launches"],
-                                         note="8 B per posting of the queries' terms (SURVEY 8d); HIP events around the select launches")
+                                         note="8 B per posting of the queries' terms (SURVEY 8d); HIP events around the select launches"
+                                              + ("; IN SITU the launch shares the chip with the dense scans and its workgroups wait for theirs "
+                                                 "-- its duration is not the kernel's: see roofline.alone.second_kernel" if alone is not None else ""))
 
     # ---- CPU baseline + parity of the TIMED result (rank 0, N = 1 only) ------------------------------
     cpu = None
