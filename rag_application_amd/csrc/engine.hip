@@ -1428,11 +1428,12 @@ static void hybrid_query_dev(hx_index* h, const float* qd, const int64_t* qip, c
       rrf(h, D, p->dense_limit, Dc, S, p->sparse_limit, Sc, B, rk, p->rrf_rank_base, p->final_limit, out_keys,
           out_cnt, st, w);
     };
-    // Round 4: the sparse stage runs on a second stream BESIDE the dense stage's tail.  Behind the last scan launch the
-    // dense stage is ~0.5 ms of small kernels (log scatter, two compactions, the exact re-score of 450 candidates per
-    // query -- a bandwidth-bound gather -- the certificate), none of which needs LDS; the sparse select pass holds every
-    // CU's LDS but is bound by its barriers, not by issue slots or bandwidth (section 10.2): the two co-reside.  (Beside
-    // the SCAN it does not pay: both kernels want a CU's whole LDS -- round 2, scripts/overlap_probe.py.)
+    // Round 4: the sparse stage runs on a second stream BESIDE the dense stage.  First beside its tail only (behind the last
+    // scan launch the dense stage is ~0.5 ms of small kernels -- log scatter, compactions, the exact re-score of 450 candidates
+    // per query, the certificate -- none of which needs LDS): +0.8 %.  Then from the start of the call (below): the select pass
+    // and the scans cannot share a CU (both want its whole LDS) but each fills the other's ragged ends, and the stage's own
+    // small kernels hide behind the scans.  (Round 1's probe, scripts/overlap_probe.py, had said no: other kernels, and the scan
+    // confined to a part of the chip.)
     bool forked = false, marked = false;
     auto mark = [&]() {                                  // the point of the caller's stream the second stream starts from
       if (!h->overlap_tail) return;
