@@ -1872,6 +1872,18 @@ def test_sparse_stage_beside_the_dense_scans_changes_no_list(eng, torch_mod, mon
             st = ix.stats()
             stats[name] = tuple(st[k] for k in ("dense_fallback_queries", "sparse_fallback_queries", "retry_queries",
                                                 "cand8_uncertified_queries", "tree_batches_redone"))
+            if name == "scan":                  # ... and the switch of the ABI (hx_set_stream_overlap), both ways
+                for B in (7, 300):
+                    Q = eng.synth_queries_dense(dim, 3, B, synth.SEED_QUERY)
+                    sp = [torch_mod.from_numpy(a).cuda() for a in synth.sparse_queries(synth.SEED_SPQUERY, 3, B, tabs)]
+                    for mode in (eng.HX_MODE_H1, eng.HX_MODE_TREE):
+                        ix.set_stream_overlap(False)
+                        k, c = ix.hybrid_query(Q, *sp, eng.make_params(P, mode=mode))
+                        ix.set_stream_overlap(True)
+                        k2, c2 = ix.hybrid_query(Q, *sp, eng.make_params(P, mode=mode))
+                        torch_mod.cuda.synchronize()
+                        for kk, cc in ((k, c), (k2, c2)):
+                            assert torch_mod.equal(kk, got[(B, mode)][0]) and torch_mod.equal(cc, got[(B, mode)][1]), ("switch", B, mode)
         finally:
             ix.close()
     # what a placement cannot change either: how many queries left the fast paths (a race would show here first)
