@@ -2305,10 +2305,12 @@ int hx_h1_nominate_async(hx_index* h, const float* qd, const int64_t* qip, const
   // list itself is consumed by this rank's own rescore step) -- on the second stream, beside the dense scan
   bool forked = false;
   hipStream_t sst = st;
-  // OFF by default: alone the call is shorter with it (1.34 -> 1.27 ms at 1.25M rows, B = 1024), but in H1Pipeline the
-  // re-score + exchange of the previous batch already run beside it on the pipeline's side stream, and a third stream in
-  // the mix made the pipelined step LONGER (1.49 -> 1.55 ms; profiles/r04_h1_small_batch.txt)
-  static const bool nom_fork = getenv("HX_DEBUG_NOM_FORK") != nullptr && atoi(getenv("HX_DEBUG_NOM_FORK")) != 0;
+  // Only for LARGE shards: alone the call is shorter with it at every size (1.34 -> 1.27 ms at 1.25M rows, B = 1024), but in
+  // H1Pipeline the re-score + exchange of the previous batch already run beside it on the pipeline's side stream, and a third
+  // stream in the mix made the pipelined step LONGER at the 8- and 4-GPU shard sizes (1.49 -> 1.55 ms at 1.25M rows, 2.68 ->
+  // 2.75 at 2.5M) and shorter only at the 2-GPU one (5.00 -> 4.93 ms at 5M rows; profiles/r04_h1_small_batch.txt)
+  static const int nom_env = getenv("HX_DEBUG_NOM_FORK") ? atoi(getenv("HX_DEBUG_NOM_FORK")) : -1;
+  const bool nom_fork = nom_env >= 0 ? nom_env != 0 : h->n >= 4000000;
   if (h->overlap_tail && nom_fork && h->n > 0) {
     ensure_side_stream(h);
     HX_HIP(hipEventRecord(h->ev_fork, st));
