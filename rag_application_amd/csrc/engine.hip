@@ -2309,7 +2309,8 @@ int hx_h1_nominate_async(hx_index* h, const float* qd, const int64_t* qip, const
   // H1Pipeline the re-score + exchange of the previous batch already run beside it on the pipeline's side stream, and a third
   // stream in the mix made the pipelined step LONGER at the 8- and 4-GPU shard sizes (1.49 -> 1.55 ms at 1.25M rows, 2.68 ->
   // 2.75 at 2.5M) and shorter only at the 2-GPU one (5.00 -> 4.93 ms at 5M rows; profiles/r04_h1_small_batch.txt)
-  static const int nom_env = getenv("HX_DEBUG_NOM_FORK") ? atoi(getenv("HX_DEBUG_NOM_FORK")) : -1;
+  const char* nom_e = getenv("HX_DEBUG_NOM_FORK");          // (read per call: the tests switch it)
+  const int nom_env = nom_e ? atoi(nom_e) : -1;
   const bool nom_fork = nom_env >= 0 ? nom_env != 0 : h->n >= 4000000;
   if (h->overlap_tail && nom_fork && h->n > 0) {
     ensure_side_stream(h);

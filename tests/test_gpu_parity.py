@@ -525,11 +525,15 @@ def _cf_exchange(eng, torch_mod, shards, Qd, tq, dl, sl, limit, k1, k2, lp, k3, 
     return k, c, int(nf.item())
 
 
+@pytest.mark.parametrize("fork", ["select pass on the caller's stream", "select pass on the second stream"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_candidates_first_exchange_equals_one_index(eng, torch_mod, synth_tables, world):
+def test_candidates_first_exchange_equals_one_index(eng, torch_mod, synth_tables, world, fork, monkeypatch):
     """hx_h1_nominate_async / hx_h1_rescore_async / hx_h1_finish (row-sharded H1, the exchange before the exact scores)
     against ONE index over the same rows and against the oracle: ids and score bits, with duplicate rows on different
-    shards (a tie the global list must order by id) and duplicate documents (equal sparse scores)."""
+    shards (a tie the global list must order by id) and duplicate documents (equal sparse scores).  `fork`: where the
+    nomination's select pass runs -- shards of 4M rows and more put it on the index's second stream, beside the dense scan
+    (HX_DEBUG_NOM_FORK forces either)."""
+    monkeypatch.setenv("HX_DEBUG_NOM_FORK", "1" if "second" in fork else "0")
     n, dim, B, dl, sl = 24000, 256, 130, 40, 25
     tabs = synth_tables
     X = O.synth_dense(O.SEED_CORPUS, 0, n, dim)
